@@ -1,0 +1,124 @@
+"""ctypes binding of oracle/libtd_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(the product package tagdust_amd never does).  The library is the CPU restatement of the
+reference's per-read HMM decoding path (oracle/td_oracle.c, pinned against the reference by
+tests/test_oracle_golden.py).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libtd_oracle.so")
+MAX_SEG = 64
+
+
+class _Model(C.Structure):
+    _fields_ = [
+        ("S", C.c_int32), ("H", C.c_int32), ("C", C.c_int32), ("avg_len", C.c_int32),
+        ("bg", C.c_float * 5),
+        ("n_hmm", C.c_int32 * MAX_SEG), ("n_col", C.c_int32 * MAX_SEG),
+        ("col_off", C.c_int32 * MAX_SEG), ("hmm_off", C.c_int32 * MAX_SEG),
+        ("skip", C.c_float * MAX_SEG), ("type", C.c_int8 * MAX_SEG),
+        ("finger_len", C.c_int32 * MAX_SEG),
+        ("trans", C.c_void_p), ("eM", C.c_void_p), ("eI", C.c_void_p),
+        ("sM", C.c_void_p), ("sI", C.c_void_p), ("label", C.c_void_p), ("A", C.c_void_p),
+    ]
+
+
+class _Params(C.Structure):
+    _fields_ = [("threshold", C.c_float), ("minlen", C.c_int32), ("dust", C.c_int32)]
+
+
+RESULT_DTYPE = np.dtype([
+    ("b_score", "<f4"), ("f_score", "<f4"), ("r_score", "<f4"), ("bar_prob", "<f4"),
+    ("Q", "<f4"), ("read_type", "<i4"), ("barcode", "<i4"), ("fingerprint", "<i4"),
+])
+
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "td_oracle.c")):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libtd_oracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.tdo_init_logsum.restype = None
+        _lib.tdo_logsum.restype = C.c_float
+        _lib.tdo_logsum.argtypes = [C.c_float, C.c_float]
+        _lib.tdo_logsum_table.restype = C.POINTER(C.c_float)
+        _lib.tdo_qvalue.restype = C.c_float
+        _lib.tdo_qvalue.argtypes = [C.c_float, C.c_float, C.c_float]
+        _lib.tdo_label_batch.restype = C.c_int
+        _lib.tdo_label_batch.argtypes = [C.POINTER(_Model), C.POINTER(_Params), C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        _lib.tdo_init_logsum()
+    return _lib
+
+
+def logsum_table():
+    p = lib().tdo_logsum_table()
+    return np.ctypeslib.as_array(p, shape=(16000,)).copy()
+
+
+class OracleModel:
+    """Holds the flattened tables (numpy, kept alive) and the C struct that points at them."""
+
+    def __init__(self, md):
+        """md: dict with S,H,C,avg_len,bg,n_hmm,n_col,skip,seg_type,seg_len,trans,eM,eI,sM,sI,label,A."""
+        self.S, self.H, self.Ccols = int(md["S"]), int(md["H"]), int(md["C"])
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        self.trans = f32(md["trans"]).reshape(self.Ccols, 9)
+        self.eM = f32(md["eM"]).reshape(self.Ccols, 5)
+        self.eI = f32(md["eI"]).reshape(self.Ccols, 5)
+        self.sM = f32(md["sM"]).reshape(self.Ccols)
+        self.sI = f32(md["sI"]).reshape(self.Ccols)
+        self.label = np.ascontiguousarray(md["label"], dtype=np.int32).reshape(self.H)
+        self.A = f32(md["A"]).reshape(self.H, self.H)
+        m = _Model()
+        m.S, m.H, m.C, m.avg_len = self.S, self.H, self.Ccols, int(md["avg_len"])
+        for i in range(5):
+            m.bg[i] = float(np.float32(md["bg"][i]))
+        co = ho = 0
+        for j in range(self.S):
+            m.n_hmm[j] = int(md["n_hmm"][j])
+            m.n_col[j] = int(md["n_col"][j])
+            m.col_off[j], m.hmm_off[j] = co, ho
+            co += m.n_hmm[j] * m.n_col[j]
+            ho += m.n_hmm[j]
+            m.skip[j] = float(np.float32(md["skip"][j]))
+            t = int(md["seg_type"][j])
+            m.type[j] = t
+            m.finger_len[j] = int(md["seg_len"][j]) if t == ord("F") else 0
+        assert co == self.Ccols and ho == self.H
+        for name in ("trans", "eM", "eI", "sM", "sI", "label", "A"):
+            setattr(m, name, getattr(self, name).ctypes.data)
+        self.c = m
+
+
+def label_batch(model, seqs, offs, threshold, minlen=16, dust=100, n_threads=1):
+    """Run the oracle over a batch.  seqs: uint8 codes (0..4) concatenated; offs: int64 [n+1].
+    Returns (results structured array, labels int8 laid out at offs[i]+i with len+1 entries,
+    seq_after uint8)."""
+    L = lib()
+    offs = np.ascontiguousarray(offs, dtype=np.int64)
+    n = len(offs) - 1
+    seq_after = np.array(seqs, dtype=np.uint8, copy=True)
+    labels = np.zeros(int(offs[-1]) + n, dtype=np.int8)
+    res = np.zeros(n, dtype=RESULT_DTYPE)
+    p = _Params(float(threshold), int(minlen), int(dust))
+    rc = L.tdo_label_batch(C.byref(model.c), C.byref(p), int(n_threads), seq_after.ctypes.data,
+                           offs.ctypes.data, n, labels.ctypes.data, res.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("tdo_label_batch failed (%d)" % rc)
+    return res, labels, seq_after
