@@ -1,0 +1,142 @@
+/*
+ * tagdust_hip.h -- C-ABI of libtagdust_hip.so: TagDust2's per-read HMM decoding path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the reference's
+ *
+ *     int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri,
+ *                  struct parameters* param, struct fasta* reference_fasta, int numseq, int mode);
+ *                                                   (src/barcode_hmm.h:342, src/barcode_hmm.c:1895-2029)
+ *
+ * i.e. the pthread fan-out over do_label_thread / do_probability_estimation (barcode_hmm.c:2174-2360), whose
+ * per-read body is backward() (:3439) -> forward_max_posterior_decoding() (:4128) -> Q value (:2320-2338) ->
+ * extract_reads() (:3172) -> dust_sequences() (:2407).  Plain C types only; every entry point returns
+ * TD_OK (0) / TD_FAIL (1) like the reference's kslOK / kslFAIL (src/kslib.h:12-16) and never calls exit().
+ * How a reference maintainer binds it is shown in INTEGRATION.md.
+ *
+ * Flow:  td_ctx_create -> td_model_upload -> td_set_params
+ *        per batch: td_batch_upload (host reads) -> td_run -> td_batch_download
+ *        end of run: td_counts_get (per-outcome / per-barcode counters, the input of the RCCL all-reduce)
+ */
+#ifndef TAGDUST_HIP_H
+#define TAGDUST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TD_OK   0   /* kslOK   */
+#define TD_FAIL 1   /* kslFAIL */
+
+#define TD_MAX_SEGMENTS 64    /* MAX_NUM_SUB_MODELS, src/barcode_hmm.h:101 */
+#define TD_MAX_HMMS     127   /* labels are signed char (src/io.h:80); the reference itself stops at 100 (barcode_hmm.c:4186) */
+#define TD_LOGSUM_SIZE  16000 /* src/misc.h:45 */
+
+/* run modes, src/barcode_hmm.h:128-132 */
+#define TD_MODE_GET_LABEL 1   /* label + Q + extraction (+ DUST)           do_label_thread            */
+#define TD_MODE_GET_PROB  4   /* Q only (threshold calibration)            do_probability_estimation  */
+
+/* extraction outcomes, src/io.h:40-46 */
+#define TD_EXTRACT_SUCCESS                    0
+#define TD_EXTRACT_FAIL_ARCHITECTURE_MISMATCH 1
+#define TD_EXTRACT_FAIL_READ_TOO_SHORT        2
+#define TD_EXTRACT_FAIL_BAR_FINGER_NOT_FOUND  3
+#define TD_EXTRACT_FAIL_MATCHES_ARTIFACTS     5
+#define TD_EXTRACT_FAIL_LOW_COMPLEXITY        6
+
+/* transition indices of td_model_desc.trans, src/barcode_hmm.h:87-96 */
+enum { TD_MM = 0, TD_MI = 1, TD_MD = 2, TD_II = 3, TD_IM = 4, TD_DD = 5, TD_DM = 6, TD_MSKIP = 7, TD_ISKIP = 8 };
+
+/* counters returned by td_counts_get: slot = outcome code 0..7, then 256 per-barcode success bins
+ * (index = barcode & 0xFF like the writer's file index, src/io.c:930) */
+#define TD_NUM_OUTCOME_SLOTS 8
+#define TD_NUM_BARCODE_BINS  256
+#define TD_NUM_COUNTERS (TD_NUM_OUTCOME_SLOTS + TD_NUM_BARCODE_BINS)
+
+typedef struct td_ctx td_ctx;
+
+/* Flattened read-architecture HMM: exactly the tables struct model_bag holds after init_model_bag()
+ * (src/barcode_hmm.h:187-272, barcode_hmm.c:5760-6011).  All floats are natural-log probabilities, log(0) = -inf.
+ * Column index of (segment j, HMM f, column g) = sum_{j'<j} n_hmm[j']*n_col[j'] + f*n_col[j] + g. */
+typedef struct td_model_desc {
+	int32_t S;                  /* mb->num_models                                      */
+	int32_t H;                  /* mb->total_hmm_num        (<= TD_MAX_HMMS)           */
+	int32_t C;                  /* total number of columns                             */
+	int32_t avg_len;            /* mb->average_raw_length                              */
+	float   bg[5];              /* model[0]->background_nuc_frequency                  */
+	const int32_t* n_hmm;       /* [S] model[j]->num_hmms                              */
+	const int32_t* n_col;       /* [S] model[j]->hmms[0]->num_columns                  */
+	const float*   skip;        /* [S] model[j]->skip                                  */
+	const int8_t*  seg_type;    /* [S] read_structure->type[j]: 'B','R','P','F','S','O','G' */
+	const int32_t* finger_len;  /* [S] strlen(sequence_matrix[j][0]) for 'F' segments (extract_reads :3196-3200), else 0 */
+	const float*   trans;       /* [C][9] hmm_column->transition                       */
+	const float*   eM;          /* [C][5] hmm_column->m_emit                           */
+	const float*   eI;          /* [C][5] hmm_column->i_emit                           */
+	const float*   sM;          /* [C]    model->silent_to_M[f][g]                     */
+	const float*   sI;          /* [C]    model->silent_to_I[f][g]                     */
+	const int32_t* label;       /* [H]    mb->label                                    */
+	const float*   A;           /* [H][H] mb->transition_matrix (0/1)                  */
+} td_model_desc;
+
+/* Per-read outputs (what run_pHMM leaves in struct read_info, src/io.h:76-91) */
+typedef struct td_read_result {
+	float   f_score;            /* mb->f_score                                          */
+	float   b_score;            /* mb->b_score                                          */
+	float   r_score;            /* mb->r_score                                          */
+	float   bar_prob;           /* ri->bar_prob before it is reset to 100 (:2343)       */
+	float   mapq;               /* ri->mapq  (Q)                                        */
+	int32_t read_type;          /* ri->read_type                                        */
+	int32_t barcode;            /* ri->barcode     ((segment << 16) | hmm), -1 if none  */
+	int32_t fingerprint;        /* ri->fingerprint ((key << 8) | len),      -1 if none  */
+} td_read_result;
+
+/* ---- context (one per GPU; replaces run_pHMM's per-thread model copies, barcode_hmm.c:1911-1922) ---- */
+int  td_ctx_create(int device, td_ctx** out);
+void td_ctx_destroy(td_ctx* ctx);
+/* last error text of this context (or of the failed td_ctx_create when ctx == NULL) */
+const char* td_last_error(const td_ctx* ctx);
+
+/* init_logsum() (src/misc.c:57-63) happens inside td_ctx_create; this returns the 16000-entry host copy */
+const float* td_logsum_table(void);
+
+/* ---- model + run parameters ---- */
+int td_model_upload(td_ctx* ctx, const td_model_desc* model);
+/* param->confidence_threshold in effect, param->minlen, param->dust (0 = off) */
+int td_set_params(td_ctx* ctx, float threshold, int32_t minlen, int32_t dust);
+
+/* ---- batches ---- */
+/* Stage a batch of reads: codes = base codes 0..4 (A,C,G,T,other: src/nuc_code.c:46-74) of all reads
+ * concatenated, offs[n_reads+1] the read boundaries (like ri[i]->seq / ri[i]->len).  Packs to 2 bit + N mask,
+ * copies to HBM.  Replaces whatever batch was resident. */
+int td_batch_upload(td_ctx* ctx, const uint8_t* codes, const int64_t* offs, int64_t n_reads);
+/* Same from ASCII FASTQ sequence lines (applies the nuc_code mapping). */
+int td_batch_upload_ascii(td_ctx* ctx, const char* bases, const int64_t* offs, int64_t n_reads);
+/* Run the hot path over the resident batch on the context's stream (asynchronous; td_sync / td_batch_download
+ * wait).  mode = TD_MODE_GET_LABEL or TD_MODE_GET_PROB.  Adds this batch's outcomes to the counters. */
+int td_run(td_ctx* ctx, int mode);
+int td_sync(td_ctx* ctx);
+/* Copy results of the resident batch back.  Any pointer may be NULL.
+ *   res      [n_reads]
+ *   labels   read i at offs[i]+i, len_i+1 bytes (ri->labels, barcode_hmm.c:4503-4514)
+ *   seq_out  read i at offs[i], len_i bytes: the sequence as extract_reads() rewrites it
+ *            (codes 0..4, non-read positions 65; barcode_hmm.c:3325-3356); untouched codes when not extracted */
+int td_batch_download(td_ctx* ctx, td_read_result* res, int8_t* labels, uint8_t* seq_out);
+
+/* ---- counters (the reference's serial outcome counting, barcode_hmm.c:354-384, done on device) ---- */
+int td_counts_reset(td_ctx* ctx);
+int td_counts_get(td_ctx* ctx, int64_t* counts /* [TD_NUM_COUNTERS] */);
+/* device pointer to the int64 counters, for an in-place RCCL all-reduce over xGMI */
+void* td_counts_device_ptr(td_ctx* ctx);
+
+/* ---- measurement hooks (bench.py) ---- */
+/* Milliseconds the last td_run's kernel took, from HIP events recorded on the context's stream. */
+int td_last_kernel_ms(td_ctx* ctx, float* ms);
+/* Number of reads resident, HBM workspace bytes, wave slots in use. */
+int td_batch_info(td_ctx* ctx, int64_t* n_reads, int64_t* workspace_bytes, int32_t* wave_slots);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAGDUST_HIP_H */

@@ -1,0 +1,514 @@
+// td_api.hip -- C-ABI host layer of libtagdust_hip.so (declared in include/tagdust_hip.h).
+//
+// Replaces the reference's run_pHMM() fan-out (src/barcode_hmm.c:1895-2029): instead of T pthreads with
+// private model copies, one context per GPU holds the flattened model in HBM and launches the decode
+// kernel (td_kernels.hip) over a resident batch.  No torch, no CPU fallback: every entry point fails
+// with TD_FAIL (and a message in td_last_error) when HIP does.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/tagdust_hip.h"
+#include "td_device.h"
+
+extern "C" hipError_t td_launch_decode(const TdKernelArgs* ka, hipStream_t stream);
+extern "C" int td_kernel_block_threads(void);
+
+static float g_logsum[TD_LOGSUM_SIZE];
+static bool g_logsum_ready = false;
+static std::string g_create_error;
+
+static void init_logsum_host()
+{
+	// init_logsum(), src/misc.c:57-63: (float) log(1. + exp((double) -i / SCALE)), SCALE = 1000.0f
+	if (g_logsum_ready) return;
+	for (int i = 0; i < TD_LOGSUM_SIZE; i++) g_logsum[i] = (float)log(1.0 + exp((double)-i / (double)1000.0f));
+	g_logsum_ready = true;
+}
+
+// prob2scaledprob(), src/misc.c:85-92
+static float p2sp(float p) { return p == 0.0f ? -INFINITY : (float)log((double)p); }
+
+struct td_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	std::string err;
+	int n_cu = 0;
+	size_t hbm_total = 0;
+
+	// model
+	bool have_model = false;
+	TdModelHeader hdr{};
+	std::vector<int32_t> label;
+	TdModelHeader* d_hdr = nullptr;
+	TdCol* d_cols = nullptr;
+	uint32_t* d_hinfo = nullptr;
+	int32_t* d_pred_off = nullptr;
+	int32_t* d_pred_idx = nullptr;
+	float* d_logsum = nullptr;
+	unsigned long long* d_counters = nullptr;
+
+	// params
+	float threshold = 0.0f;
+	int32_t minlen = 16, dust = 100;
+
+	// batch
+	int64_t n_reads = 0;
+	int32_t n_tiles = 0, lmax = 0, nw2 = 0, nw1 = 0;
+	std::vector<int64_t> offs;
+	std::vector<uint8_t> codes_host; // kept for td_batch_download(seq_out)
+	uint32_t* d_packed = nullptr; size_t cap_packed = 0;
+	int32_t* d_lens = nullptr;    size_t cap_lens = 0;
+	uint8_t* d_out = nullptr;     size_t cap_out = 0;   // all per-read outputs in one allocation
+	uint8_t* d_ws = nullptr;      size_t cap_ws = 0;
+	TdWsLayout lay{};
+	int32_t n_slots = 0;
+	bool ran = false;
+	float last_ms = -1.0f;
+};
+
+static int fail(td_ctx* c, const char* fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	if (c) c->err = buf; else g_create_error = buf;
+	return TD_FAIL;
+}
+
+#define HIPCHK(c, call)                                                                       \
+	do {                                                                                      \
+		hipError_t e_ = (call);                                                               \
+		if (e_ != hipSuccess) return fail((c), "%s failed: %s", #call, hipGetErrorString(e_)); \
+	} while (0)
+
+template <typename T>
+static int ensure(td_ctx* c, T** p, size_t* cap, size_t bytes)
+{
+	if (*cap >= bytes && *p) return TD_OK;
+	if (*p) { HIPCHK(c, hipFree(*p)); *p = nullptr; *cap = 0; }
+	if (bytes == 0) bytes = 256;
+	HIPCHK(c, hipMalloc((void**)p, bytes));
+	*cap = bytes;
+	return TD_OK;
+}
+
+extern "C" const float* td_logsum_table(void)
+{
+	init_logsum_host();
+	return g_logsum;
+}
+
+extern "C" const char* td_last_error(const td_ctx* ctx)
+{
+	return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" int td_ctx_create(int device, td_ctx** out)
+{
+	if (!out) return fail(nullptr, "td_ctx_create: out is NULL");
+	*out = nullptr;
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0)
+		return fail(nullptr, "td_ctx_create: no HIP device available (%s) -- this library has no CPU path",
+		            e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+	if (device < 0 || device >= ndev) return fail(nullptr, "td_ctx_create: device %d out of range (0..%d)", device, ndev - 1);
+	td_ctx* c = new td_ctx();
+	c->device = device;
+	hipDeviceProp_t prop;
+	if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+		delete c;
+		return fail(nullptr, "td_ctx_create: cannot select device %d", device);
+	}
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+		std::string arch = prop.gcnArchName;
+		delete c;
+		return fail(nullptr, "td_ctx_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, arch.c_str());
+	}
+	c->n_cu = prop.multiProcessorCount;
+	c->hbm_total = prop.totalGlobalMem;
+	init_logsum_host();
+	bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+	          hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
+	          hipMalloc((void**)&c->d_logsum, sizeof(float) * TD_LOGSUM_LIVE) == hipSuccess &&
+	          hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * TD_NUM_COUNTERS) == hipSuccess &&
+	          hipMemcpy(c->d_logsum, g_logsum, sizeof(float) * TD_LOGSUM_LIVE, hipMemcpyHostToDevice) == hipSuccess &&
+	          hipMemset(c->d_counters, 0, sizeof(unsigned long long) * TD_NUM_COUNTERS) == hipSuccess;
+	if (!ok) {
+		td_ctx_destroy(c);
+		return fail(nullptr, "td_ctx_create: HIP resource allocation failed: %s", hipGetErrorString(hipGetLastError()));
+	}
+	*out = c;
+	return TD_OK;
+}
+
+extern "C" void td_ctx_destroy(td_ctx* c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	void* bufs[] = { c->d_hdr, c->d_cols, c->d_hinfo, c->d_pred_off, c->d_pred_idx, c->d_logsum, c->d_counters,
+	                 c->d_packed, c->d_lens, c->d_out, c->d_ws };
+	for (void* p : bufs) if (p) (void)hipFree(p);
+	if (c->ev0) (void)hipEventDestroy(c->ev0);
+	if (c->ev1) (void)hipEventDestroy(c->ev1);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
+{
+	if (!c || !m) return fail(c, "td_model_upload: NULL argument");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (m->S < 1 || m->S > TD_MAX_SEGMENTS) return fail(c, "td_model_upload: %d segments (1..%d supported)", m->S, TD_MAX_SEGMENTS);
+	if (m->H < 1 || m->H > TD_MAX_HMMS) return fail(c, "td_model_upload: %d HMMs (1..%d supported)", m->H, TD_MAX_HMMS);
+	if (!m->n_hmm || !m->n_col || !m->skip || !m->seg_type || !m->finger_len || !m->trans || !m->eM || !m->eI ||
+	    !m->sM || !m->sI || !m->label || !m->A)
+		return fail(c, "td_model_upload: NULL table pointer");
+	TdModelHeader h{};
+	h.S = m->S; h.H = m->H; h.C = m->C; h.avg_len = m->avg_len;
+	for (int i = 0; i < 5; i++) h.bg[i] = m->bg[i];
+	// random model constants, barcode_hmm.c:4520,4523 (float/double mix exactly as written there)
+	h.r_stay = p2sp((float)(1.0 - (1.0 / (double)(float)m->avg_len)));
+	h.r_exit = p2sp((float)(1.0 / (double)(float)m->avg_len));
+	int co = 0, ho = 0, req = 0, maxc = 0;
+	for (int j = 0; j < m->S; j++) {
+		if (m->n_hmm[j] < 1 || m->n_col[j] < 1) return fail(c, "td_model_upload: segment %d has %d HMMs x %d columns", j, m->n_hmm[j], m->n_col[j]);
+		TdSeg& s = h.seg[j];
+		s.n_hmm = m->n_hmm[j]; s.n_col = m->n_col[j]; s.col_off = co; s.hmm_off = ho;
+		s.skip = m->skip[j]; s.skip_live = !(m->skip[j] == -INFINITY); s.type = m->seg_type[j];
+		co += s.n_hmm * s.n_col; ho += s.n_hmm;
+		if (m->seg_type[j] == 'F') req += m->finger_len[j];
+		if (s.n_col > maxc) maxc = s.n_col;
+	}
+	if (co != m->C || ho != m->H) return fail(c, "td_model_upload: inconsistent sizes (columns %d vs C %d, HMMs %d vs H %d)", co, m->C, ho, m->H);
+	h.required_finger_len = req;
+	h.max_ncol = maxc;
+
+	std::vector<TdCol> cols(m->C);
+	for (int k = 0; k < m->C; k++) {
+		TdCol& q = cols[k];
+		memset(&q, 0, sizeof q);
+		uint32_t fl = 0;
+		for (int t = 0; t < 9; t++) { q.t[t] = m->trans[k * 9 + t]; if (!(q.t[t] == -INFINITY)) fl |= 1u << t; }
+		q.sM = m->sM[k]; if (!(q.sM == -INFINITY)) fl |= TDF_SM;
+		q.sI = m->sI[k]; if (!(q.sI == -INFINITY)) fl |= TDF_SI;
+		for (int e = 0; e < 5; e++) { q.eM[e] = m->eM[k * 5 + e]; q.eI[e] = m->eI[k * 5 + e]; }
+		q.flags = fl;
+	}
+	// per-HMM info for extract_reads (barcode_hmm.c:3205-3226): type | segment | hmm | decoy
+	std::vector<uint32_t> hinfo(m->H);
+	for (int hh = 0; hh < m->H; hh++) {
+		const int seg = m->label[hh] & 0xFFFF, f = (m->label[hh] >> 16) & 0x7FFF;
+		if (seg >= m->S) return fail(c, "td_model_upload: label[%d] names segment %d", hh, seg);
+		uint32_t v = (uint32_t)(uint8_t)m->seg_type[seg] | ((uint32_t)seg << 8) | ((uint32_t)f << 16);
+		if (m->seg_type[seg] == 'B' && f == m->n_hmm[seg] - 1) v |= 0x80000000u; // all-N decoy, interface.c:521-527
+		hinfo[hh] = v;
+	}
+	// label transition matrix -> predecessor lists (only u < v; staying in v is handled in the kernel)
+	std::vector<int32_t> poff(m->H + 1, 0), pidx;
+	for (int v = 0; v < m->H; v++) {
+		poff[v] = (int32_t)pidx.size();
+		for (int u = 0; u < v; u++) {
+			const float a = m->A[u * m->H + v];
+			if (a != 0.0f && a != 1.0f) return fail(c, "td_model_upload: transition matrix entry [%d][%d] = %g is not 0/1", u, v, a);
+			if (a == 1.0f) pidx.push_back(u);
+		}
+		if (m->A[v * m->H + v] != 1.0f) return fail(c, "td_model_upload: transition matrix diagonal [%d] must be 1", v);
+	}
+	poff[m->H] = (int32_t)pidx.size();
+	if (pidx.empty()) pidx.push_back(0);
+
+	void* old[] = { c->d_hdr, c->d_cols, c->d_hinfo, c->d_pred_off, c->d_pred_idx };
+	for (void* p : old) if (p) HIPCHK(c, hipFree(p));
+	c->d_hdr = nullptr; c->d_cols = nullptr; c->d_hinfo = nullptr; c->d_pred_off = nullptr; c->d_pred_idx = nullptr;
+	c->have_model = false;
+	HIPCHK(c, hipMalloc((void**)&c->d_hdr, sizeof h));
+	HIPCHK(c, hipMalloc((void**)&c->d_cols, sizeof(TdCol) * cols.size()));
+	HIPCHK(c, hipMalloc((void**)&c->d_hinfo, sizeof(uint32_t) * hinfo.size()));
+	HIPCHK(c, hipMalloc((void**)&c->d_pred_off, sizeof(int32_t) * poff.size()));
+	HIPCHK(c, hipMalloc((void**)&c->d_pred_idx, sizeof(int32_t) * pidx.size()));
+	HIPCHK(c, hipMemcpy(c->d_hdr, &h, sizeof h, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_cols, cols.data(), sizeof(TdCol) * cols.size(), hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_hinfo, hinfo.data(), sizeof(uint32_t) * hinfo.size(), hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_pred_off, poff.data(), sizeof(int32_t) * poff.size(), hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_pred_idx, pidx.data(), sizeof(int32_t) * pidx.size(), hipMemcpyHostToDevice));
+	c->hdr = h;
+	c->label.assign(m->label, m->label + m->H);
+	c->have_model = true;
+	c->ran = false;
+	return TD_OK;
+}
+
+extern "C" int td_set_params(td_ctx* c, float threshold, int32_t minlen, int32_t dust)
+{
+	if (!c) return TD_FAIL;
+	c->threshold = threshold; c->minlen = minlen; c->dust = dust;
+	return TD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// batches
+// ---------------------------------------------------------------------------------------------------------
+static inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+static void make_layout(TdWsLayout& L, int S, int H, int C, int lmax, int max_ncol)
+{
+	int64_t o = 0;
+	L.codes = o; o = align256(o + (int64_t)(lmax + 2) * TD_WAVE);
+	L.sb = o;    o = align256(o + (int64_t)(S + 1) * (lmax + 2) * TD_WAVE * 4);
+	L.sf = o;    o = align256(o + (int64_t)(S + 1) * (lmax + 2) * TD_WAVE * 4);
+	L.bw = o;    o = align256(o + (int64_t)C * lmax * TD_WAVE * 8);
+	L.fwrow = o; o = align256(o + (int64_t)max_ncol * TD_WAVE * 8);
+	L.dp = o;    o = align256(o + (int64_t)lmax * H * TD_WAVE * 4);
+	L.path = o;  o = align256(o + (int64_t)lmax * H * TD_WAVE);
+	L.acc = o;   o = align256(o + (int64_t)H * TD_WAVE * 4);
+	L.total = o; o = align256(o + (int64_t)H * TD_WAVE * 4);
+	L.dust = o;  o = align256(o + (int64_t)64 * TD_WAVE);
+	L.slot_bytes = o;
+}
+
+// output block: SoA arrays over n_tiles*64 reads, then keep words, then labels
+struct OutLayout { int64_t f, b, r, bar, q, type, barcode, finger, keep, labels, total; };
+static OutLayout out_layout(int64_t n_tiles, int lmax, int nw1)
+{
+	OutLayout o; int64_t p = 0; const int64_t n = n_tiles * TD_WAVE;
+	o.f = p; p = align256(p + n * 4); o.b = p; p = align256(p + n * 4); o.r = p; p = align256(p + n * 4);
+	o.bar = p; p = align256(p + n * 4); o.q = p; p = align256(p + n * 4); o.type = p; p = align256(p + n * 4);
+	o.barcode = p; p = align256(p + n * 4); o.finger = p; p = align256(p + n * 4);
+	o.keep = p; p = align256(p + n_tiles * nw1 * TD_WAVE * 4);
+	o.labels = p; p = align256(p + n_tiles * (int64_t)(lmax + 1) * TD_WAVE);
+	o.total = p;
+	return o;
+}
+
+static int upload_common(td_ctx* c, const uint8_t* codes, const char* ascii, const int64_t* offs, int64_t n)
+{
+	if (!c) return TD_FAIL;
+	if (!c->have_model) return fail(c, "td_batch_upload: no model uploaded");
+	if ((!codes && !ascii) || !offs || n < 0) return fail(c, "td_batch_upload: bad arguments");
+	HIPCHK(c, hipSetDevice(c->device));
+	int lmax = 1;
+	for (int64_t i = 0; i < n; i++) {
+		const int64_t l = offs[i + 1] - offs[i];
+		if (l < 0 || l > 100000) return fail(c, "td_batch_upload: read %lld has length %lld", (long long)i, (long long)l);
+		if (l > lmax) lmax = (int)l;
+	}
+	const int64_t n_tiles = (n + TD_WAVE - 1) / TD_WAVE;
+	const int nw2 = (lmax + 15) / 16, nw1 = (lmax + 31) / 32;
+	const int64_t tile_words = (int64_t)(nw2 + nw1) * TD_WAVE;
+
+	// pack: 2 bits per base + 1 bit "is N" per base, lane-interleaved per tile so a wave reads 256 contiguous bytes per word
+	std::vector<uint32_t> packed((size_t)(n_tiles * tile_words), 0u);
+	std::vector<int32_t> lens((size_t)(n_tiles * TD_WAVE), 0);
+	c->codes_host.resize((size_t)offs[n]);
+	static uint8_t asc2code[256];
+	static bool asc_ready = false;
+	if (!asc_ready) { // init_nuc_code(), src/nuc_code.c:46-74: ACGTU (either case) -> 0..3(3), everything else 4
+		for (int k = 0; k < 256; k++) asc2code[k] = 4;
+		asc2code['A'] = asc2code['a'] = 0; asc2code['C'] = asc2code['c'] = 1; asc2code['G'] = asc2code['g'] = 2;
+		asc2code['T'] = asc2code['t'] = 3; asc2code['U'] = asc2code['u'] = 3;
+		asc_ready = true;
+	}
+	for (int64_t i = 0; i < n; i++) {
+		const int64_t tile = i / TD_WAVE; const int lane = (int)(i % TD_WAVE);
+		const int l = (int)(offs[i + 1] - offs[i]);
+		lens[(size_t)i] = l;
+		uint32_t* pk = packed.data() + tile * tile_words;
+		for (int k = 0; k < l; k++) {
+			uint8_t cd = codes ? codes[offs[i] + k] : asc2code[(uint8_t)ascii[offs[i] + k]];
+			if (cd > 4) cd = 4;
+			c->codes_host[(size_t)(offs[i] + k)] = cd;
+			if (cd == 4) pk[(nw2 + (k >> 5)) * TD_WAVE + lane] |= 1u << (k & 31);
+			else pk[(k >> 4) * TD_WAVE + lane] |= (uint32_t)cd << (2 * (k & 15));
+		}
+	}
+	if (ensure(c, &c->d_packed, &c->cap_packed, packed.size() * 4) != TD_OK) return TD_FAIL;
+	if (ensure(c, &c->d_lens, &c->cap_lens, lens.size() * 4) != TD_OK) return TD_FAIL;
+	if (!packed.empty()) HIPCHK(c, hipMemcpyAsync(c->d_packed, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, c->stream));
+	if (!lens.empty()) HIPCHK(c, hipMemcpyAsync(c->d_lens, lens.data(), lens.size() * 4, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+
+	c->n_reads = n; c->n_tiles = (int32_t)n_tiles; c->lmax = lmax; c->nw2 = nw2; c->nw1 = nw1;
+	c->offs.assign(offs, offs + n + 1);
+	c->ran = false;
+
+	// outputs + workspace
+	const OutLayout ol = out_layout(n_tiles, lmax, nw1);
+	if (ensure(c, &c->d_out, &c->cap_out, (size_t)ol.total) != TD_OK) return TD_FAIL;
+	make_layout(c->lay, c->hdr.S, c->hdr.H, c->hdr.C, lmax, c->hdr.max_ncol);
+	// wave slots: enough to fill the chip (2 workgroups of 4 waves per CU share the LDS), bounded by HBM
+	const int wpb = td_kernel_block_threads() / TD_WAVE;
+	int64_t want = (int64_t)c->n_cu * 2 * wpb;
+	if (const char* e = getenv("TD_WAVE_SLOTS")) { const long v = atol(e); if (v > 0) want = v; }
+	size_t free_b = 0, total_b = 0;
+	HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+	const int64_t budget = (int64_t)((double)(free_b + c->cap_ws) * 0.85);
+	int64_t slots = want;
+	if (slots * c->lay.slot_bytes > budget) slots = budget / c->lay.slot_bytes;
+	if (slots > n_tiles) slots = n_tiles;
+	if (slots < 1) {
+		if (n_tiles == 0) slots = 1;
+		else return fail(c, "td_batch_upload: workspace of %lld bytes per wave does not fit in HBM", (long long)c->lay.slot_bytes);
+	}
+	slots = (slots + wpb - 1) / wpb * wpb; // whole workgroups
+	if (ensure(c, &c->d_ws, &c->cap_ws, (size_t)(slots * c->lay.slot_bytes)) != TD_OK) return TD_FAIL;
+	c->n_slots = (int32_t)slots;
+	return TD_OK;
+}
+
+extern "C" int td_batch_upload(td_ctx* c, const uint8_t* codes, const int64_t* offs, int64_t n)
+{
+	return upload_common(c, codes, nullptr, offs, n);
+}
+
+extern "C" int td_batch_upload_ascii(td_ctx* c, const char* bases, const int64_t* offs, int64_t n)
+{
+	return upload_common(c, nullptr, bases, offs, n);
+}
+
+extern "C" int td_run(td_ctx* c, int mode)
+{
+	if (!c) return TD_FAIL;
+	if (!c->have_model) return fail(c, "td_run: no model uploaded");
+	if (mode != TD_MODE_GET_LABEL && mode != TD_MODE_GET_PROB) return fail(c, "td_run: unsupported mode %d", mode);
+	HIPCHK(c, hipSetDevice(c->device));
+	if (c->n_tiles == 0) { c->ran = true; c->last_ms = 0.0f; return TD_OK; }
+	const OutLayout ol = out_layout(c->n_tiles, c->lmax, c->nw1);
+	TdKernelArgs ka{};
+	ka.hdr = c->d_hdr; ka.cols = c->d_cols; ka.hinfo = c->d_hinfo;
+	ka.pred_off = c->d_pred_off; ka.pred_idx = c->d_pred_idx; ka.logsum = c->d_logsum;
+	ka.packed = c->d_packed; ka.lens = c->d_lens;
+	ka.n_tiles = c->n_tiles; ka.n_slots = c->n_slots; ka.lmax = c->lmax; ka.nw2 = c->nw2; ka.nw1 = c->nw1;
+	ka.mode = mode; ka.threshold = c->threshold; ka.minlen = c->minlen; ka.dust = c->dust; ka.want_labels = 1;
+	ka.out_f = (float*)(c->d_out + ol.f); ka.out_b = (float*)(c->d_out + ol.b); ka.out_r = (float*)(c->d_out + ol.r);
+	ka.out_bar = (float*)(c->d_out + ol.bar); ka.out_q = (float*)(c->d_out + ol.q);
+	ka.out_type = (int32_t*)(c->d_out + ol.type); ka.out_barcode = (int32_t*)(c->d_out + ol.barcode);
+	ka.out_finger = (int32_t*)(c->d_out + ol.finger);
+	ka.out_keep = (uint32_t*)(c->d_out + ol.keep); ka.out_labels = (int8_t*)(c->d_out + ol.labels);
+	ka.counters = c->d_counters;
+	ka.ws = c->d_ws; ka.lay = c->lay;
+	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+	HIPCHK(c, td_launch_decode(&ka, c->stream));
+	HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+	c->ran = true;
+	c->last_ms = -1.0f;
+	return TD_OK;
+}
+
+extern "C" int td_sync(td_ctx* c)
+{
+	if (!c) return TD_FAIL;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return TD_OK;
+}
+
+extern "C" int td_last_kernel_ms(td_ctx* c, float* ms)
+{
+	if (!c || !ms) return TD_FAIL;
+	if (!c->ran) return fail(c, "td_last_kernel_ms: nothing has run");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (c->last_ms < 0.0f && c->n_tiles > 0) {
+		HIPCHK(c, hipEventSynchronize(c->ev1));
+		HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+	}
+	*ms = c->last_ms;
+	return TD_OK;
+}
+
+extern "C" int td_batch_info(td_ctx* c, int64_t* n_reads, int64_t* workspace_bytes, int32_t* wave_slots)
+{
+	if (!c) return TD_FAIL;
+	if (n_reads) *n_reads = c->n_reads;
+	if (workspace_bytes) *workspace_bytes = (int64_t)c->n_slots * c->lay.slot_bytes;
+	if (wave_slots) *wave_slots = c->n_slots;
+	return TD_OK;
+}
+
+extern "C" int td_batch_download(td_ctx* c, td_read_result* res, int8_t* labels, uint8_t* seq_out)
+{
+	if (!c) return TD_FAIL;
+	if (!c->ran) return fail(c, "td_batch_download: td_run has not been called on this batch");
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	const int64_t n = c->n_reads;
+	if (n == 0) return TD_OK;
+	const OutLayout ol = out_layout(c->n_tiles, c->lmax, c->nw1);
+	const int64_t np = (int64_t)c->n_tiles * TD_WAVE;
+	if (res) {
+		std::vector<uint8_t> h((size_t)ol.keep);
+		HIPCHK(c, hipMemcpy(h.data(), c->d_out, (size_t)ol.keep, hipMemcpyDeviceToHost));
+		const float* f = (const float*)(h.data() + ol.f); const float* b = (const float*)(h.data() + ol.b);
+		const float* r = (const float*)(h.data() + ol.r); const float* bar = (const float*)(h.data() + ol.bar);
+		const float* q = (const float*)(h.data() + ol.q); const int32_t* ty = (const int32_t*)(h.data() + ol.type);
+		const int32_t* bc = (const int32_t*)(h.data() + ol.barcode); const int32_t* fg = (const int32_t*)(h.data() + ol.finger);
+		for (int64_t i = 0; i < n; i++) {
+			res[i].f_score = f[i]; res[i].b_score = b[i]; res[i].r_score = r[i]; res[i].bar_prob = bar[i];
+			res[i].mapq = q[i]; res[i].read_type = ty[i]; res[i].barcode = bc[i]; res[i].fingerprint = fg[i];
+		}
+		(void)np;
+	}
+	if (labels) {
+		const size_t bytes = (size_t)c->n_tiles * (c->lmax + 1) * TD_WAVE;
+		std::vector<int8_t> h(bytes);
+		HIPCHK(c, hipMemcpy(h.data(), c->d_out + ol.labels, bytes, hipMemcpyDeviceToHost));
+		for (int64_t i = 0; i < n; i++) {
+			const int64_t tile = i / TD_WAVE; const int lane = (int)(i % TD_WAVE);
+			const int l = (int)(c->offs[i + 1] - c->offs[i]);
+			const int8_t* src = h.data() + tile * (int64_t)(c->lmax + 1) * TD_WAVE;
+			int8_t* dst = labels + c->offs[i] + i;
+			for (int k = 0; k <= l; k++) dst[k] = src[k * TD_WAVE + lane];
+		}
+	}
+	if (seq_out) {
+		const size_t words = (size_t)c->n_tiles * c->nw1 * TD_WAVE;
+		std::vector<uint32_t> h(words);
+		HIPCHK(c, hipMemcpy(h.data(), c->d_out + ol.keep, words * 4, hipMemcpyDeviceToHost));
+		for (int64_t i = 0; i < n; i++) {
+			const int64_t tile = i / TD_WAVE; const int lane = (int)(i % TD_WAVE);
+			const int l = (int)(c->offs[i + 1] - c->offs[i]);
+			const uint32_t* kw = h.data() + tile * (int64_t)c->nw1 * TD_WAVE;
+			for (int k = 0; k < l; k++) {
+				const bool keep = (kw[(k >> 5) * TD_WAVE + lane] >> (k & 31)) & 1u;
+				seq_out[c->offs[i] + k] = keep ? c->codes_host[(size_t)(c->offs[i] + k)] : 65; // spacer byte, barcode_hmm.c:3348
+			}
+		}
+	}
+	return TD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// counters
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int td_counts_reset(td_ctx* c)
+{
+	if (!c) return TD_FAIL;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * TD_NUM_COUNTERS, c->stream));
+	return TD_OK;
+}
+
+extern "C" int td_counts_get(td_ctx* c, int64_t* counts)
+{
+	if (!c || !counts) return TD_FAIL;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, hipMemcpy(counts, c->d_counters, sizeof(int64_t) * TD_NUM_COUNTERS, hipMemcpyDeviceToHost));
+	return TD_OK;
+}
+
+extern "C" void* td_counts_device_ptr(td_ctx* c) { return c ? (void*)c->d_counters : nullptr; }

@@ -1,0 +1,96 @@
+// td_device.h -- device-side data layout shared by the HIP kernels (td_kernels.hip) and the C-ABI host
+// layer (td_api.hip).  gfx950 only: wave64, one read per lane.
+#pragma once
+#include <stdint.h>
+
+#define TD_WAVE 64
+// live part of the logsum table: logsum() only indexes it when (max-min) < 15.7f, and
+// (int)(15.699999f * 1000.0f) == 15699 (reference src/misc.c:72-78)
+#define TD_LOGSUM_LIVE 15700
+
+// per-column flags: bit k set <=> parameter k is live (!= -inf), so the term it gates can contribute
+enum : uint32_t {
+	TDF_MM = 1u << 0, TDF_MI = 1u << 1, TDF_MD = 1u << 2, TDF_II = 1u << 3, TDF_IM = 1u << 4,
+	TDF_DD = 1u << 5, TDF_DM = 1u << 6, TDF_MSKIP = 1u << 7, TDF_ISKIP = 1u << 8,
+	TDF_SM = 1u << 9, TDF_SI = 1u << 10,
+};
+
+// One HMM column: everything the DP reads for it, 96 bytes, read with wave-uniform (scalar) loads.
+struct TdCol {
+	float    t[9];     // transition[MM,MI,MD,II,IM,DD,DM,MSKIP,ISKIP]   (barcode_hmm.h:87-96)
+	float    sM, sI;   // silent_to_M[f][g], silent_to_I[f][g]
+	float    eM[5];    // m_emit
+	float    eI[5];    // i_emit
+	uint32_t flags;
+	uint32_t pad[2];
+};
+static_assert(sizeof(TdCol) == 96, "TdCol layout");
+
+struct TdSeg {
+	int32_t n_hmm, n_col, col_off, hmm_off;
+	float   skip;
+	int32_t skip_live;   // skip != -inf
+	int32_t type;        // 'B','R',...
+	int32_t pad;
+};
+
+// per-HMM info for extraction (extract_reads, barcode_hmm.c:3205-3226)
+//   bits 0..7 segment type char, 8..15 segment index, 16..30 hmm index in segment, 31 = is the all-N decoy of a B segment
+struct TdModelHeader {
+	int32_t S, H, C, avg_len;
+	float   bg[5];
+	float   r_stay;      // log(1 - 1/avg_len)    (barcode_hmm.c:4520)
+	float   r_exit;      // log(1/avg_len)        (barcode_hmm.c:4523)
+	int32_t required_finger_len;
+	int32_t max_ncol;
+	int32_t pad[3];
+	TdSeg   seg[64];
+};
+
+// Per-wave-slot workspace layout (byte offsets from the slot base); every array is lane-interleaved
+// [...][64 lanes] so that each wave-level access is one contiguous 64/256/512-byte run.
+struct TdWsLayout {
+	int64_t slot_bytes;
+	int64_t codes;   // u8   [lmax+2][64]            unpacked base codes x_0..x_{lmax+1}
+	int64_t sb;      // f32  [S+1][lmax+2][64]       silent_backward rows; row S = previous_silent
+	int64_t sf;      // f32  [S+1][lmax+2][64]       row 0 = previous_silent, row j+1 = silent_forward of segment j
+	int64_t bw;      // f32x2[C][lmax][64]           (M_backward, I_backward)[col][i-1]
+	int64_t fwrow;   // f32x2[max_ncol][64]          forward row i-1 for segments too long for registers
+	int64_t dp;      // f32  [lmax][H][64]           posterior label probabilities, rows i = 1..lmax
+	int64_t path;    // u8   [lmax][H][64]
+	int64_t acc;     // f32  [H][64]                 running label-DP row
+	int64_t total;   // f32  [H][64]                 total_prob[h]
+	int64_t dust;    // u8   [64][64]                DUST triplet counters
+};
+
+struct TdKernelArgs {
+	const TdModelHeader* __restrict__ hdr;
+	const TdCol*  __restrict__ cols;       // [C]
+	const uint32_t* __restrict__ hinfo;    // [H]
+	const int32_t*  __restrict__ pred_off; // [H+1]  CSR of allowed label predecessors u < v (A[u][v] == 1)
+	const int32_t*  __restrict__ pred_idx;
+	const float*  __restrict__ logsum;     // [TD_LOGSUM_LIVE] in HBM, staged into LDS per workgroup
+	// batch (tile = 64 consecutive reads)
+	const uint32_t* __restrict__ packed;   // [n_tiles][nw2 + nw1][64]  2-bit words then N-mask words
+	const int32_t*  __restrict__ lens;     // [n_tiles*64]  (0 = padding lane)
+	int32_t n_tiles, n_slots, lmax, nw2, nw1;
+	int32_t mode;                          // TD_MODE_*
+	float   threshold;
+	int32_t minlen, dust;
+	int32_t want_labels;
+	// outputs
+	float*   __restrict__ out_f;           // [n_tiles*64] each
+	float*   __restrict__ out_b;
+	float*   __restrict__ out_r;
+	float*   __restrict__ out_bar;
+	float*   __restrict__ out_q;
+	int32_t* __restrict__ out_type;
+	int32_t* __restrict__ out_barcode;
+	int32_t* __restrict__ out_finger;
+	uint32_t* __restrict__ out_keep;       // [n_tiles][nw1][64]  bit k of read = position k is kept (label is an R segment)
+	int8_t*  __restrict__ out_labels;      // [n_tiles][lmax+1][64]
+	unsigned long long* __restrict__ counters; // [TD_NUM_COUNTERS]
+	// workspace
+	uint8_t* __restrict__ ws;
+	TdWsLayout lay;
+};

@@ -1,0 +1,175 @@
+"""ctypes mirror of include/tagdust_hip.h (the drop-in boundary for the reference's run_pHMM(),
+src/barcode_hmm.h:342).  Fails loudly when the HIP library is missing or no MI355X is present."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtagdust_hip.so")
+
+MODE_GET_LABEL = 1
+MODE_GET_PROB = 4
+NUM_OUTCOME_SLOTS = 8
+NUM_BARCODE_BINS = 256
+NUM_COUNTERS = NUM_OUTCOME_SLOTS + NUM_BARCODE_BINS
+
+# every symbol include/tagdust_hip.h declares
+ABI_SYMBOLS = [
+    "td_ctx_create", "td_ctx_destroy", "td_last_error", "td_logsum_table", "td_model_upload", "td_set_params",
+    "td_batch_upload", "td_batch_upload_ascii", "td_run", "td_sync", "td_batch_download", "td_counts_reset",
+    "td_counts_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_batch_info",
+]
+
+RESULT_DTYPE = np.dtype([
+    ("f_score", "<f4"), ("b_score", "<f4"), ("r_score", "<f4"), ("bar_prob", "<f4"), ("mapq", "<f4"),
+    ("read_type", "<i4"), ("barcode", "<i4"), ("fingerprint", "<i4"),
+])
+
+
+class TdError(RuntimeError):
+    pass
+
+
+class _ModelDesc(C.Structure):
+    _fields_ = [
+        ("S", C.c_int32), ("H", C.c_int32), ("C", C.c_int32), ("avg_len", C.c_int32), ("bg", C.c_float * 5),
+        ("n_hmm", C.c_void_p), ("n_col", C.c_void_p), ("skip", C.c_void_p), ("seg_type", C.c_void_p),
+        ("finger_len", C.c_void_p), ("trans", C.c_void_p), ("eM", C.c_void_p), ("eI", C.c_void_p),
+        ("sM", C.c_void_p), ("sI", C.c_void_p), ("label", C.c_void_p), ("A", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libtagdust_hip.so (no GPU needed for this step)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TdError("%s is missing: run `python -m tagdust_amd.build` (or __graft_entry__.build()); "
+                      "there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.td_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.td_ctx_destroy.argtypes = [C.c_void_p]
+    lib.td_ctx_destroy.restype = None
+    lib.td_last_error.argtypes = [C.c_void_p]
+    lib.td_last_error.restype = C.c_char_p
+    lib.td_logsum_table.restype = C.POINTER(C.c_float)
+    lib.td_model_upload.argtypes = [C.c_void_p, C.POINTER(_ModelDesc)]
+    lib.td_set_params.argtypes = [C.c_void_p, C.c_float, C.c_int32, C.c_int32]
+    lib.td_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.td_batch_upload_ascii.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.td_run.argtypes = [C.c_void_p, C.c_int]
+    lib.td_sync.argtypes = [C.c_void_p]
+    lib.td_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.td_counts_reset.argtypes = [C.c_void_p]
+    lib.td_counts_get.argtypes = [C.c_void_p, C.c_void_p]
+    lib.td_counts_device_ptr.argtypes = [C.c_void_p]
+    lib.td_counts_device_ptr.restype = C.c_void_p
+    lib.td_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.td_batch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    _lib = lib
+    return lib
+
+
+class TagdustHip:
+    """One context per GPU (the analogue of run_pHMM's per-thread model copies)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        if self.lib.td_ctx_create(int(device), C.byref(h)) != 0:
+            raise TdError(self.lib.td_last_error(None).decode())
+        self.h = h
+        self._keep = None
+        self.offs = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.td_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise TdError(self.lib.td_last_error(self.h).decode())
+
+    def upload_model(self, md):
+        """md: mapping with S,H,C,avg_len,bg,n_hmm,n_col,skip,seg_type,seg_len,trans,eM,eI,sM,sI,label,A
+        (the tables of struct model_bag; same keys as the golden fixtures)."""
+        S, H, Cc = int(md["S"]), int(md["H"]), int(md["C"])
+        a = {
+            "n_hmm": np.ascontiguousarray(md["n_hmm"], np.int32), "n_col": np.ascontiguousarray(md["n_col"], np.int32),
+            "skip": np.ascontiguousarray(md["skip"], np.float32),
+            "seg_type": np.ascontiguousarray(md["seg_type"], np.int32).astype(np.int8),
+            "finger_len": np.where(np.asarray(md["seg_type"]) == ord("F"), np.asarray(md["seg_len"]), 0).astype(np.int32),
+            "trans": np.ascontiguousarray(md["trans"], np.float32).reshape(Cc, 9),
+            "eM": np.ascontiguousarray(md["eM"], np.float32).reshape(Cc, 5),
+            "eI": np.ascontiguousarray(md["eI"], np.float32).reshape(Cc, 5),
+            "sM": np.ascontiguousarray(md["sM"], np.float32).reshape(Cc),
+            "sI": np.ascontiguousarray(md["sI"], np.float32).reshape(Cc),
+            "label": np.ascontiguousarray(md["label"], np.int32).reshape(H),
+            "A": np.ascontiguousarray(md["A"], np.float32).reshape(H, H),
+        }
+        d = _ModelDesc()
+        d.S, d.H, d.C, d.avg_len = S, H, Cc, int(md["avg_len"])
+        for i in range(5):
+            d.bg[i] = float(np.float32(md["bg"][i]))
+        for k, v in a.items():
+            setattr(d, k, v.ctypes.data)
+        self._keep = a
+        self._chk(self.lib.td_model_upload(self.h, C.byref(d)))
+
+    def set_params(self, threshold, minlen=16, dust=100):
+        self._chk(self.lib.td_set_params(self.h, float(threshold), int(minlen), int(dust)))
+
+    def upload_batch(self, codes, offs):
+        codes = np.ascontiguousarray(codes, np.uint8)
+        self.offs = np.ascontiguousarray(offs, np.int64)
+        self._chk(self.lib.td_batch_upload(self.h, codes.ctypes.data, self.offs.ctypes.data, len(self.offs) - 1))
+
+    def upload_batch_ascii(self, bases, offs):
+        buf = np.frombuffer(bases, dtype=np.uint8) if isinstance(bases, (bytes, bytearray)) else np.ascontiguousarray(bases, np.uint8)
+        self.offs = np.ascontiguousarray(offs, np.int64)
+        self._chk(self.lib.td_batch_upload_ascii(self.h, buf.ctypes.data, self.offs.ctypes.data, len(self.offs) - 1))
+
+    def run(self, mode=MODE_GET_LABEL):
+        self._chk(self.lib.td_run(self.h, int(mode)))
+
+    def sync(self):
+        self._chk(self.lib.td_sync(self.h))
+
+    def download(self, labels=True, seq=True):
+        n = len(self.offs) - 1
+        res = np.zeros(n, RESULT_DTYPE)
+        lab = np.zeros(int(self.offs[-1]) + n, np.int8) if labels else None
+        sq = np.zeros(int(self.offs[-1]), np.uint8) if seq else None
+        self._chk(self.lib.td_batch_download(self.h, res.ctypes.data, lab.ctypes.data if labels else None,
+                                             sq.ctypes.data if seq else None))
+        return res, lab, sq
+
+    def counts_reset(self):
+        self._chk(self.lib.td_counts_reset(self.h))
+
+    def counts(self):
+        c = np.zeros(NUM_COUNTERS, np.int64)
+        self._chk(self.lib.td_counts_get(self.h, c.ctypes.data))
+        return c
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._chk(self.lib.td_last_kernel_ms(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    def batch_info(self):
+        n, w, s = C.c_int64(), C.c_int64(), C.c_int32()
+        self._chk(self.lib.td_batch_info(self.h, C.byref(n), C.byref(w), C.byref(s)))
+        return int(n.value), int(w.value), int(s.value)

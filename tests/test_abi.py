@@ -1,0 +1,46 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/tagdust_hip.h declares, and refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tagdust_amd import lib as tdlib
+from tagdust_amd import build as tdbuild
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def library():
+    tdbuild.build()
+    return tdlib.load_library()
+
+
+def test_header_symbols_all_exported(library):
+    hdr = open(os.path.join(REPO, "include", "tagdust_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(td_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no prototypes parsed"
+    assert declared == set(tdlib.ABI_SYMBOLS)
+    for name in sorted(declared):
+        assert hasattr(library, name), name
+
+
+def test_logsum_table_host_copy(library):
+    # init_logsum(), src/misc.c:57-63
+    p = library.td_logsum_table()
+    t = np.ctypeslib.as_array(p, shape=(16000,))
+    i = np.arange(16000, dtype=np.float64)
+    want = np.log(1.0 + np.exp(-i / 1000.0)).astype(np.float32)
+    assert np.array_equal(t.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback(library):
+    with pytest.raises(tdlib.TdError) as e:
+        tdlib.TagdustHip(0)
+    assert "no CPU path" in str(e.value) or "HIP" in str(e.value)

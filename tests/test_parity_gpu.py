@@ -1,0 +1,126 @@
+"""Parity tests proper: the HIP path (through the C-ABI, tagdust_amd/libtagdust_hip.so) against
+ (a) the committed fixtures produced by the reference itself (tests/golden/*.npz) and
+ (b) the CPU oracle on fresh seeded inputs.
+Bit-exact for labels / outcomes / barcodes / fingerprints / extracted sequences and for the float
+scores (f, b, r, bar_prob); Q within 1e-4 (BASELINE.json north_star) -- in practice also bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, GOLDEN_NAMES
+
+pytestmark = pytest.mark.gpu
+
+Q_TOL = 1e-4
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from tagdust_amd import TagdustHip
+    c = TagdustHip(0)
+    yield c
+    c.close()
+
+
+def _run(ctx, g, seq=None, offs=None, threshold=None):
+    ctx.upload_model(g)
+    ctx.set_params(float(g["threshold"]) if threshold is None else threshold, int(g["minlen"]), int(g["dust"]))
+    ctx.upload_batch(g["seq"] if seq is None else seq, g["offs"] if offs is None else offs)
+    ctx.counts_reset()
+    ctx.run()
+    return ctx.download()
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_hip_vs_reference_fixture(ctx, name):
+    g = load_golden(name)
+    res, labels, seq_after = _run(ctx, g)
+    assert np.array_equal(_bits(res["b_score"]), _bits(g["b_score"]))
+    assert np.array_equal(_bits(res["f_score"]), _bits(g["f_score"]))
+    assert np.array_equal(_bits(res["r_score"]), _bits(g["r_score"]))
+    assert np.array_equal(_bits(res["bar_prob"]), _bits(g["bar_prob"].astype(np.float32)))
+    assert np.array_equal(labels, g["labels"])
+    assert np.allclose(res["mapq"], g["mapq"], rtol=0, atol=Q_TOL)
+    assert np.array_equal(res["read_type"], g["read_type"])
+    assert np.array_equal(res["barcode"], g["barcode"])
+    assert np.array_equal(res["fingerprint"], g["fingerprint"])
+    assert np.array_equal(seq_after, g["seq_after"])
+    # device-side outcome counters == serial counting (barcode_hmm.c:354-384)
+    cnt = ctx.counts()
+    for code in range(8):
+        assert cnt[code] == int((g["read_type"] == code).sum())
+    ok = g["read_type"] == 0
+    bins = np.bincount((g["barcode"][ok & (g["barcode"] >= 0)] & 0xFF), minlength=256)
+    assert np.array_equal(cnt[8:], bins)
+
+
+@pytest.mark.parametrize("name", ["c2_b4_r", "c3_b6_s_r_p", "scen2_endloss", "umi_f_s_r"])
+def test_hip_vs_oracle_fresh_reads(ctx, name):
+    """Fresh seeded reads (uniform random with occasional N, ragged lengths incl. 1-base reads) through
+    the fixture's model: HIP == oracle."""
+    from oracle import pyoracle
+    g = load_golden(name)
+    rng = np.random.RandomState(1234)
+    n = 700
+    lens = rng.randint(int(g["S"]) + 1, int(g["lens"].max()) + 1, n)
+    lens[:5] = int(g["lens"].max())
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    seq = rng.randint(0, 4, int(offs[-1])).astype(np.uint8)
+    seq[rng.random_sample(len(seq)) < 0.01] = 4
+    # plant real reads too so that successes occur
+    src_off = g["offs"]
+    for i in range(0, n, 3):
+        k = i % int(g["n_reads"])
+        s = g["seq"][src_off[k]:src_off[k + 1]]
+        m = min(len(s), lens[i])
+        seq[offs[i]:offs[i] + m] = s[:m]
+    model = pyoracle.OracleModel(g)
+    ores, olab, oseq = pyoracle.label_batch(model, seq, offs, float(g["threshold"]), int(g["minlen"]), int(g["dust"]), 4)
+    res, labels, seq_after = _run(ctx, g, seq, offs)
+    for k in ("b_score", "f_score", "r_score", "bar_prob"):
+        assert np.array_equal(_bits(res[k]), _bits(ores[k])), k
+    assert np.array_equal(labels, olab)
+    assert np.allclose(res["mapq"], ores["Q"], rtol=0, atol=Q_TOL)
+    for k in ("read_type", "barcode", "fingerprint"):
+        assert np.array_equal(res[k], ores[k]), k
+    assert np.array_equal(seq_after, oseq)
+
+
+def test_empty_batch(ctx):
+    g = load_golden("c2_b4_r")
+    res, labels, seq_after = _run(ctx, g, np.zeros(0, np.uint8), np.zeros(1, np.int64))
+    assert len(res) == 0 and len(labels) == 0 and len(seq_after) == 0
+
+
+def test_long_segment_fallback_matches_oracle(ctx):
+    """A 20-column partial segment exercises the workspace-row path (segments > 16 columns)."""
+    from oracle import pyoracle
+    g = load_golden("scen2_p_b_r_p")
+    # widen the trailing P segment by repeating its middle column -- tables only, the oracle and the
+    # HIP path see the same flattened model, which is all this test needs
+    S, ncol, nh = int(g["S"]), g["n_col"].copy(), g["n_hmm"].copy()
+    last = S - 1
+    c0 = int((nh[:last] * ncol[:last]).sum())
+    old = int(ncol[last])
+    new = 20
+    rep = [0] + [1] * (new - old + 1) + list(range(2, old))
+    idx = list(range(c0)) + [c0 + r for r in rep]
+    g2 = dict(g)
+    for k in ("trans", "eM", "eI", "sM", "sI"):
+        g2[k] = g[k][idx]
+    ncol[last] = new
+    g2["n_col"] = ncol
+    g2["C"] = len(idx)
+    seg_len = g["seg_len"].copy(); seg_len[last] = new
+    g2["seg_len"] = seg_len
+    model = pyoracle.OracleModel(g2)
+    ores, olab, oseq = pyoracle.label_batch(model, g["seq"], g["offs"], float(g["threshold"]), int(g["minlen"]), int(g["dust"]), 4)
+    res, labels, seq_after = _run(ctx, g2)
+    for k in ("b_score", "f_score", "r_score", "bar_prob"):
+        assert np.array_equal(_bits(res[k]), _bits(ores[k])), k
+    assert np.array_equal(labels, olab)
+    assert np.array_equal(res["read_type"], ores["read_type"])
+    assert np.array_equal(seq_after, oseq)
