@@ -39,7 +39,7 @@ const float* tdo_logsum_table(void)
 	return g_logsum_table;
 }
 
-float tdo_logsum(float a, float b)
+static inline float logsum_(float a, float b)
 {
 	/* misc.c:72-78 */
 	const float mx = (a > b) ? a : b;
@@ -47,7 +47,8 @@ float tdo_logsum(float a, float b)
 	if (mn == NEG_INF || (mx - mn) >= 15.7f) return mx;
 	return mx + g_logsum_table[(int)((mx - mn) * 1000.0f)];
 }
-#define LS(a, b) tdo_logsum((a), (b))
+float tdo_logsum(float a, float b) { return logsum_(a, b); }
+#define LS(a, b) logsum_((a), (b))
 
 /* scaledprob2prob(), misc.c:98-105: float in, exp() in double, float out */
 static float sp2p(float p)

@@ -44,19 +44,45 @@
 // d = max-min is +inf when min == -inf and NaN when both are -inf; "d < 15.7f" is false for both, which
 // returns max exactly like the reference.  The index of dead lanes is clamped into the table.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float lsum(const float* __restrict__ T, float a, float b)
+__shared__ float g_T[TD_LOGSUM_LIVE];
+
+struct LdsTable {};   // tag: the table is the file-scope LDS array, never a generic pointer (a generic pointer
+                      // turns every lookup into a flat_load that waits on vmcnt AND lgkmcnt)
+
+__device__ __forceinline__ float lsum(LdsTable, float a, float b)
 {
 	const float mx = (a > b) ? a : b;
 	const float mn = (a < b) ? a : b;
 	const float d = mx - mn;
 	const float dc = fminf(d, __uint_as_float(0x417B3332u)); // largest float < 15.7f
 	const int idx = (int)(dc * 1000.0f);
-	const float t = T[idx];
+	const float t = g_T[idx];
 	return (d < 15.7f) ? (mx + t) : mx;
 }
 
+// Model tables are read through the constant address space: with a wave-uniform index the compiler then
+// emits scalar loads (s_load_dword*) instead of per-lane global loads.
+#define TD_CONST __attribute__((address_space(4)))
+typedef const TdCol TD_CONST* ccol_ptr;
+typedef const TdModelHeader TD_CONST* chdr_ptr;
+typedef const float TD_CONST* cfloat_ptr;
+typedef const int32_t TD_CONST* cint_ptr;
+typedef const uint32_t TD_CONST* cuint_ptr;
+template <typename T> __device__ __forceinline__ const T TD_CONST* as_const(const T* p)
+{
+	return (const T TD_CONST*)(uintptr_t)p;
+}
+
+__device__ __forceinline__ TdSeg load_seg(chdr_ptr hd, int j)
+{
+	TdSeg s;
+	s.n_hmm = hd->seg[j].n_hmm; s.n_col = hd->seg[j].n_col; s.col_off = hd->seg[j].col_off; s.hmm_off = hd->seg[j].hmm_off;
+	s.skip = hd->seg[j].skip; s.skip_live = hd->seg[j].skip_live; s.type = hd->seg[j].type; s.pad = 0;
+	return s;
+}
+
 // emission lookup with a per-lane base code and wave-uniform table (5 scalars)
-__device__ __forceinline__ float emit5(const float* __restrict__ e, int c)
+__device__ __forceinline__ float emit5(cfloat_ptr e, int c)
 {
 	float r = e[4];
 	r = (c == 3) ? e[3] : r;
@@ -67,7 +93,6 @@ __device__ __forceinline__ float emit5(const float* __restrict__ e, int c)
 }
 
 struct WaveCtx {
-	const float* T;        // LDS logsum table
 	uint8_t* slot;         // this wave's workspace slot
 	int lane;
 	int len;               // this lane's read length (0 = idle lane)
@@ -82,13 +107,13 @@ __device__ __forceinline__ float* ws_f32(const WaveCtx& w, int64_t off) { return
 //   P  = silent_backward of segment j+1 (or previous_silent), Cs = silent_backward of segment j
 // ---------------------------------------------------------------------------------------------------------
 template <int NCOL>
-__device__ __forceinline__ void bwd_hmm_reg(const WaveCtx& w, const TdCol* __restrict__ cp,
+__device__ __forceinline__ void bwd_hmm_reg(const WaveCtx& w, ccol_ptr cp,
                                             const uint8_t* __restrict__ codes, const float* __restrict__ P,
                                             float* __restrict__ Cs, float2* __restrict__ bw,
                                             bool first_f, bool skip_live, float skipj)
 {
 	constexpr int K = NCOL - 1;
-	const float* T = w.T;
+	const LdsTable T{};
 	float Mn[NCOL], In[NCOL];
 #pragma unroll
 	for (int g = 0; g < NCOL; g++) { Mn[g] = NEG_INF; In[g] = NEG_INF; }
@@ -102,7 +127,7 @@ __device__ __forceinline__ void bwd_hmm_reg(const WaveCtx& w, const TdCol* __res
 			float Mc[NCOL], Ic[NCOL];
 			float Dp;
 			{   // last column, :3518-3543
-				const TdCol& q = cp[K];
+				const TdCol TD_CONST& q = cp[K];
 				const uint32_t fl = q.flags;
 				float M = Pn + q.t[7];
 				float I = Pn + q.t[8];
@@ -114,8 +139,8 @@ __device__ __forceinline__ void bwd_hmm_reg(const WaveCtx& w, const TdCol* __res
 			}
 #pragma unroll
 			for (int g = K - 1; g >= 0; --g) { // :3544-3586
-				const TdCol& q = cp[g];
-				const TdCol& qp = cp[g + 1];
+				const TdCol TD_CONST& q = cp[g];
+				const TdCol TD_CONST& qp = cp[g + 1];
 				const uint32_t fl = q.flags;
 				const float epc = emit5(qp.eM, c);
 				const float eic = emit5(q.eI, c);
@@ -146,13 +171,13 @@ __device__ __forceinline__ void bwd_hmm_reg(const WaveCtx& w, const TdCol* __res
 
 // Same recurrence for segments longer than TD_MAX_REG_NCOL columns: row i+1 is re-read from the
 // spilled backward rows (they are exactly what the previous iteration stored).
-__device__ __noinline__ void bwd_hmm_mem(const WaveCtx& w, int ncol, const TdCol* __restrict__ cp,
+__device__ __forceinline__ void bwd_hmm_mem(const WaveCtx& w, int ncol, ccol_ptr cp,
                                          const uint8_t* __restrict__ codes, const float* __restrict__ P,
                                          float* __restrict__ Cs, float2* __restrict__ bw,
                                          bool first_f, bool skip_live, float skipj)
 {
 	const int K = ncol - 1;
-	const float* T = w.T;
+	const LdsTable T{};
 	int c = 0;
 	for (int i = w.tmax; i >= 1; --i) {
 		if (i <= w.len) {
@@ -163,7 +188,7 @@ __device__ __noinline__ void bwd_hmm_mem(const WaveCtx& w, int ncol, const TdCol
 			float Mcp, Dp; // M, D of column g+1 at row i
 			float2 nxp;    // (M,I) of column g+1 at row i+1
 			{
-				const TdCol& q = cp[K];
+				const TdCol TD_CONST& q = cp[K];
 				const uint32_t fl = q.flags;
 				nxp = top ? make_float2(NEG_INF, NEG_INF) : bw[((int64_t)K * w.lmax + i) * TD_WAVE + w.lane];
 				float M = Pn + q.t[7];
@@ -176,8 +201,8 @@ __device__ __noinline__ void bwd_hmm_mem(const WaveCtx& w, int ncol, const TdCol
 				Mcp = M; Dp = NEG_INF;
 			}
 			for (int g = K - 1; g >= 0; --g) {
-				const TdCol& q = cp[g];
-				const TdCol& qp = cp[g + 1];
+				const TdCol TD_CONST& q = cp[g];
+				const TdCol TD_CONST& qp = cp[g + 1];
 				const uint32_t fl = q.flags;
 				const float2 nx = top ? make_float2(NEG_INF, NEG_INF) : bw[((int64_t)g * w.lmax + i) * TD_WAVE + w.lane];
 				const float epc = emit5(qp.eM, c);
@@ -215,14 +240,14 @@ __device__ __forceinline__ float post_prob(float lp)
 }
 
 template <int NCOL>
-__device__ __forceinline__ float fwd_hmm_reg(const WaveCtx& w, const TdCol* __restrict__ cp,
+__device__ __forceinline__ float fwd_hmm_reg(const WaveCtx& w, ccol_ptr cp,
                                              const uint8_t* __restrict__ codes, const float* __restrict__ P,
                                              float* __restrict__ Cs, const float2* __restrict__ bw,
                                              float* __restrict__ dp_h, int H, float b,
                                              bool first_f, bool skip_live, float skipj)
 {
 	constexpr int K = NCOL - 1;
-	const float* T = w.T;
+	const LdsTable T{};
 	float Mp[NCOL], Ip[NCOL];
 #pragma unroll
 	for (int g = 0; g < NCOL; g++) { Mp[g] = NEG_INF; Ip[g] = NEG_INF; }
@@ -237,7 +262,7 @@ __device__ __forceinline__ float fwd_hmm_reg(const WaveCtx& w, const TdCol* __re
 			float Dc;
 			float acc = NEG_INF;
 			{   // column 0, :4220-4268
-				const TdCol& q = cp[0];
+				const TdCol TD_CONST& q = cp[0];
 				const uint32_t fl = q.flags;
 				const float2 B = bw[((int64_t)0 * w.lmax + (i - 1)) * TD_WAVE + w.lane];
 				const float em = emit5(q.eM, c);
@@ -259,8 +284,8 @@ __device__ __forceinline__ float fwd_hmm_reg(const WaveCtx& w, const TdCol* __re
 			}
 #pragma unroll
 			for (int g = 1; g <= K; ++g) { // :4271-4334
-				const TdCol& q = cp[g];
-				const TdCol& qp = cp[g - 1];
+				const TdCol TD_CONST& q = cp[g];
+				const TdCol TD_CONST& qp = cp[g - 1];
 				const uint32_t fl = q.flags, flp = qp.flags;
 				const float2 B = bw[((int64_t)g * w.lmax + (i - 1)) * TD_WAVE + w.lane];
 				float M = Pm + q.sM;
@@ -291,14 +316,14 @@ __device__ __forceinline__ float fwd_hmm_reg(const WaveCtx& w, const TdCol* __re
 }
 
 // long segments: row i-1 kept in the workspace (fwrow[g] = (M_forward, I_forward)[g][i-1])
-__device__ __noinline__ float fwd_hmm_mem(const WaveCtx& w, int ncol, const TdCol* __restrict__ cp,
+__device__ __forceinline__ float fwd_hmm_mem(const WaveCtx& w, int ncol, ccol_ptr cp,
                                           const uint8_t* __restrict__ codes, const float* __restrict__ P,
                                           float* __restrict__ Cs, const float2* __restrict__ bw,
                                           float2* __restrict__ fwrow, float* __restrict__ dp_h, int H, float b,
                                           bool first_f, bool skip_live, float skipj)
 {
 	const int K = ncol - 1;
-	const float* T = w.T;
+	const LdsTable T{};
 	for (int g = 0; g < ncol; g++) fwrow[g * TD_WAVE + w.lane] = make_float2(NEG_INF, NEG_INF);
 	float tot = NEG_INF;
 	for (int i = 1; i <= w.tmax; ++i) {
@@ -310,7 +335,7 @@ __device__ __noinline__ float fwd_hmm_mem(const WaveCtx& w, int ncol, const TdCo
 			float Mcp, Dc;      // M, D of column g-1 at row i
 			float2 pvp;         // (M,I) of column g-1 at row i-1
 			{
-				const TdCol& q = cp[0];
+				const TdCol TD_CONST& q = cp[0];
 				const uint32_t fl = q.flags;
 				const float2 B = bw[((int64_t)0 * w.lmax + (i - 1)) * TD_WAVE + w.lane];
 				pvp = fwrow[0 * TD_WAVE + w.lane];
@@ -333,8 +358,8 @@ __device__ __noinline__ float fwd_hmm_mem(const WaveCtx& w, int ncol, const TdCo
 				Mcp = M;
 			}
 			for (int g = 1; g <= K; ++g) {
-				const TdCol& q = cp[g];
-				const TdCol& qp = cp[g - 1];
+				const TdCol TD_CONST& q = cp[g];
+				const TdCol TD_CONST& qp = cp[g - 1];
 				const uint32_t fl = q.flags, flp = qp.flags;
 				const float2 B = bw[((int64_t)g * w.lmax + (i - 1)) * TD_WAVE + w.lane];
 				const float2 pv = fwrow[g * TD_WAVE + w.lane];
@@ -379,7 +404,7 @@ __device__ __noinline__ float fwd_hmm_mem(const WaveCtx& w, int ncol, const TdCo
 
 // one segment, all its HMMs (templated on the column count so the f loop stays a scalar loop)
 template <int NCOL>
-__device__ __noinline__ void bwd_segment_reg(const WaveCtx& w, const TdSeg sg, const TdCol* __restrict__ cols,
+__device__ __forceinline__ void bwd_segment_reg(const WaveCtx& w, const TdSeg sg, ccol_ptr cols,
                                              const uint8_t* __restrict__ codes, const float* __restrict__ P,
                                              float* __restrict__ Cs, float2* __restrict__ bwbase)
 {
@@ -391,7 +416,7 @@ __device__ __noinline__ void bwd_segment_reg(const WaveCtx& w, const TdSeg sg, c
 }
 
 template <int NCOL>
-__device__ __noinline__ void fwd_segment_reg(const WaveCtx& w, const TdSeg sg, const TdCol* __restrict__ cols,
+__device__ __forceinline__ void fwd_segment_reg(const WaveCtx& w, const TdSeg sg, ccol_ptr cols,
                                              const uint8_t* __restrict__ codes, const float* __restrict__ P,
                                              float* __restrict__ Cs, const float2* __restrict__ bwbase,
                                              float* __restrict__ dp, float* __restrict__ total, int H, float b)
@@ -408,10 +433,10 @@ __device__ __noinline__ void fwd_segment_reg(const WaveCtx& w, const TdSeg sg, c
 // ---------------------------------------------------------------------------------------------------------
 // the kernel: a persistent wave walks tiles slot, slot + n_slots, ...
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TD_BLOCK) void td_decode_kernel(const TdKernelArgs ka)
+__global__ __launch_bounds__(TD_BLOCK, 2) void td_decode_kernel(const TdKernelArgs ka)
 {
-	__shared__ float T[TD_LOGSUM_LIVE];
-	for (int k = threadIdx.x; k < TD_LOGSUM_LIVE; k += TD_BLOCK) T[k] = ka.logsum[k];
+	const LdsTable T{};
+	for (int k = threadIdx.x; k < TD_LOGSUM_LIVE; k += TD_BLOCK) g_T[k] = ka.logsum[k];
 	__syncthreads();
 
 	const int lane = threadIdx.x & (TD_WAVE - 1);
@@ -419,13 +444,15 @@ __global__ __launch_bounds__(TD_BLOCK) void td_decode_kernel(const TdKernelArgs 
 	const int slot = blockIdx.x * TD_WAVES_PER_BLOCK + wave_in_block;
 	if (slot >= ka.n_slots) return;
 
-	const TdModelHeader& hd = *ka.hdr;
+	const TdModelHeader TD_CONST& hd = *as_const(ka.hdr);
+	const ccol_ptr cols_c = as_const(ka.cols);
+	const cint_ptr pred_off = as_const(ka.pred_off);
+	const cint_ptr pred_idx = as_const(ka.pred_idx);
 	const int S = hd.S, H = hd.H;
 	const int lmax = ka.lmax;
 	const int rowlen = (lmax + 2) * TD_WAVE; // floats per silent row
 
 	WaveCtx w;
-	w.T = T;
 	w.slot = ka.ws + (int64_t)slot * ka.lay.slot_bytes;
 	w.lane = lane;
 	w.lmax = lmax;
@@ -480,14 +507,14 @@ __global__ __launch_bounds__(TD_BLOCK) void td_decode_kernel(const TdKernelArgs 
 				SB[(int64_t)j * rowlen + (len + 1) * TD_WAVE + lane] = run;
 			}
 			for (int j = S - 1; j >= 0; j--) {
-				const TdSeg sg = hd.seg[j];
+				const TdSeg sg = load_seg(&hd, j);
 				const float* P = SB + (int64_t)(j + 1) * rowlen;
 				float* Cs = SB + (int64_t)j * rowlen;
 				TD_DISPATCH_NCOL(sg.n_col,
-					bwd_segment_reg<NC>(w, sg, ka.cols, codes, P, Cs, BW),
+					bwd_segment_reg<NC>(w, sg, cols_c, codes, P, Cs, BW),
 					for (int f = 0; f < sg.n_hmm; f++) {
 						const int col0 = sg.col_off + f * sg.n_col;
-						bwd_hmm_mem(w, sg.n_col, ka.cols + col0, codes, P, Cs, BW + (int64_t)col0 * lmax * TD_WAVE,
+						bwd_hmm_mem(w, sg.n_col, cols_c + col0, codes, P, Cs, BW + (int64_t)col0 * lmax * TD_WAVE,
 						            f == 0, sg.skip_live != 0, sg.skip);
 					})
 			}
@@ -509,15 +536,15 @@ __global__ __launch_bounds__(TD_BLOCK) void td_decode_kernel(const TdKernelArgs 
 				SF[(int64_t)(j + 1) * rowlen + lane] = run;
 			}
 			for (int j = 0; j < S; j++) {
-				const TdSeg sg = hd.seg[j];
+				const TdSeg sg = load_seg(&hd, j);
 				const float* P = SF + (int64_t)j * rowlen;
 				float* Cs = SF + (int64_t)(j + 1) * rowlen;
 				TD_DISPATCH_NCOL(sg.n_col,
-					fwd_segment_reg<NC>(w, sg, ka.cols, codes, P, Cs, BW, DP, TOTAL, H, b_use),
+					fwd_segment_reg<NC>(w, sg, cols_c, codes, P, Cs, BW, DP, TOTAL, H, b_use),
 					for (int f = 0; f < sg.n_hmm; f++) {
 						const int col0 = sg.col_off + f * sg.n_col;
 						const int h = sg.hmm_off + f;
-						const float tot = fwd_hmm_mem(w, sg.n_col, ka.cols + col0, codes, P, Cs,
+						const float tot = fwd_hmm_mem(w, sg.n_col, cols_c + col0, codes, P, Cs,
 						                              BW + (int64_t)col0 * lmax * TD_WAVE, FWROW,
 						                              DP + (int64_t)h * TD_WAVE, H, b_use, f == 0, sg.skip_live != 0, sg.skip);
 						TOTAL[h * TD_WAVE + lane] = tot;
@@ -596,9 +623,9 @@ __global__ __launch_bounds__(TD_BLOCK) void td_decode_kernel(const TdKernelArgs 
 					for (int v = H - 1; v >= 0; v--) {
 						float m = -1.0f;
 						int mv = 0;
-						const int p0 = ka.pred_off[v], p1 = ka.pred_off[v + 1];
+						const int p0 = pred_off[v], p1 = pred_off[v + 1];
 						for (int p = p0; p < p1; p++) {      // predecessors u < v in ascending order
-							const int u = ka.pred_idx[p];
+							const int u = pred_idx[p];
 							const float au = ACC[u * TD_WAVE + lane];
 							if (au > m) { m = au; mv = u; }
 						}
