@@ -101,7 +101,15 @@ const char* td_last_error(const td_ctx* ctx);
 const float* td_logsum_table(void);
 
 /* ---- model + run parameters ---- */
+/* Uploads the tables and (option "specialize", default 1) compiles the decode kernel specialised for this
+ * model with hiprtc -- a few seconds, once per architecture.  A compile failure is TD_FAIL, not a fallback. */
 int td_model_upload(td_ctx* ctx, const td_model_desc* model);
+/* Options, set before td_model_upload:  "specialize" 1 = model-specialised kernel (default; env TD_SPECIALIZE),
+ * 0 = the generic ahead-of-time kernel that reads the model from HBM. */
+int td_set_option(td_ctx* ctx, const char* name, int32_t value);
+/* The HIP source td_model_upload would compile for this model (no GPU needed).  Returns its length; copies at
+ * most cap-1 bytes + NUL into buf when buf != NULL. */
+int64_t td_spec_source(const td_model_desc* model, char* buf, int64_t cap);
 /* param->confidence_threshold in effect, param->minlen, param->dust (0 = off) */
 int td_set_params(td_ctx* ctx, float threshold, int32_t minlen, int32_t dust);
 

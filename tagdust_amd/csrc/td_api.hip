@@ -16,6 +16,7 @@
 
 #include "../../include/tagdust_hip.h"
 #include "td_device.h"
+#include "td_jit.h"
 
 extern "C" hipError_t td_launch_decode(const TdKernelArgs* ka, hipStream_t stream);
 extern "C" int td_kernel_block_threads(void);
@@ -54,6 +55,14 @@ struct td_ctx {
 	int32_t* d_pred_idx = nullptr;
 	float* d_logsum = nullptr;
 	unsigned long long* d_counters = nullptr;
+
+	// model-specialised kernel (td_spec_kernel.inc through hiprtc)
+	int specialize = 1;
+	bool spec_ready = false;
+	hipModule_t spec_mod = nullptr;
+	hipFunction_t spec_fn = nullptr;
+	std::vector<int32_t> m_n_hmm, m_n_col;
+	TdSpecLayout slay{};
 
 	// params
 	float threshold = 0.0f;
@@ -136,6 +145,7 @@ extern "C" int td_ctx_create(int device, td_ctx** out)
 		return fail(nullptr, "td_ctx_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, arch.c_str());
 	}
 	c->n_cu = prop.multiProcessorCount;
+	if (const char* e = getenv("TD_SPECIALIZE")) c->specialize = atoi(e) != 0;
 	c->hbm_total = prop.totalGlobalMem;
 	init_logsum_host();
 	bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -160,6 +170,7 @@ extern "C" void td_ctx_destroy(td_ctx* c)
 	void* bufs[] = { c->d_hdr, c->d_cols, c->d_hinfo, c->d_pred_off, c->d_pred_idx, c->d_logsum, c->d_counters,
 	                 c->d_packed, c->d_lens, c->d_out, c->d_ws };
 	for (void* p : bufs) if (p) (void)hipFree(p);
+	if (c->spec_mod) (void)hipModuleUnload(c->spec_mod);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -248,9 +259,36 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 	HIPCHK(c, hipMemcpy(c->d_pred_idx, pidx.data(), sizeof(int32_t) * pidx.size(), hipMemcpyHostToDevice));
 	c->hdr = h;
 	c->label.assign(m->label, m->label + m->H);
+	c->m_n_hmm.assign(m->n_hmm, m->n_hmm + m->S);
+	c->m_n_col.assign(m->n_col, m->n_col + m->S);
 	c->have_model = true;
 	c->ran = false;
+	c->n_reads = 0; c->n_tiles = 0;
+
+	// model-specialised kernel: compile now (seconds); a failure is an error, never a silent fallback
+	if (c->spec_mod) { HIPCHK(c, hipModuleUnload(c->spec_mod)); c->spec_mod = nullptr; }
+	c->spec_fn = nullptr; c->spec_ready = false;
+	if (c->specialize) {
+		std::vector<char> code;
+		std::string log;
+		if (td_spec_compile(m, code, log) != TD_OK) return fail(c, "td_model_upload: specialised kernel did not compile: %.400s", log.c_str());
+		HIPCHK(c, hipModuleLoadData(&c->spec_mod, code.data()));
+		HIPCHK(c, hipModuleGetFunction(&c->spec_fn, c->spec_mod, "td_spec_kernel"));
+		c->spec_ready = true;
+	}
 	return TD_OK;
+}
+
+extern "C" int td_set_option(td_ctx* c, const char* name, int32_t value)
+{
+	if (!c || !name) return TD_FAIL;
+	if (!strcmp(name, "specialize")) {
+		if (c->have_model && (value != 0) != (c->specialize != 0))
+			return fail(c, "td_set_option: set \"specialize\" before td_model_upload");
+		c->specialize = value != 0;
+		return TD_OK;
+	}
+	return fail(c, "td_set_option: unknown option %s", name);
 }
 
 extern "C" int td_set_params(td_ctx* c, float threshold, int32_t minlen, int32_t dust)
@@ -350,6 +388,14 @@ static int upload_common(td_ctx* c, const uint8_t* codes, const char* ascii, con
 	const OutLayout ol = out_layout(n_tiles, lmax, nw1);
 	if (ensure(c, &c->d_out, &c->cap_out, (size_t)ol.total) != TD_OK) return TD_FAIL;
 	make_layout(c->lay, c->hdr.S, c->hdr.H, c->hdr.C, lmax, c->hdr.max_ncol);
+	int64_t slot_bytes = c->lay.slot_bytes;
+	if (c->spec_ready) {
+		td_model_desc md{};
+		md.S = c->hdr.S; md.H = c->hdr.H; md.C = c->hdr.C;
+		md.n_hmm = c->m_n_hmm.data(); md.n_col = c->m_n_col.data();
+		td_spec_layout(c->slay, &md, lmax);
+		slot_bytes = c->slay.slot_bytes;
+	}
 	// wave slots: enough to fill the chip (2 workgroups of 4 waves per CU share the LDS), bounded by HBM
 	const int wpb = td_kernel_block_threads() / TD_WAVE;
 	int64_t want = (int64_t)c->n_cu * 2 * wpb;
@@ -358,14 +404,14 @@ static int upload_common(td_ctx* c, const uint8_t* codes, const char* ascii, con
 	HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
 	const int64_t budget = (int64_t)((double)(free_b + c->cap_ws) * 0.85);
 	int64_t slots = want;
-	if (slots * c->lay.slot_bytes > budget) slots = budget / c->lay.slot_bytes;
+	if (slots * slot_bytes > budget) slots = budget / slot_bytes;
 	if (slots > n_tiles) slots = n_tiles;
 	if (slots < 1) {
 		if (n_tiles == 0) slots = 1;
-		else return fail(c, "td_batch_upload: workspace of %lld bytes per wave does not fit in HBM", (long long)c->lay.slot_bytes);
+		else return fail(c, "td_batch_upload: workspace of %lld bytes per wave does not fit in HBM", (long long)slot_bytes);
 	}
 	slots = (slots + wpb - 1) / wpb * wpb; // whole workgroups
-	if (ensure(c, &c->d_ws, &c->cap_ws, (size_t)(slots * c->lay.slot_bytes)) != TD_OK) return TD_FAIL;
+	if (ensure(c, &c->d_ws, &c->cap_ws, (size_t)(slots * slot_bytes)) != TD_OK) return TD_FAIL;
 	c->n_slots = (int32_t)slots;
 	return TD_OK;
 }
@@ -402,7 +448,23 @@ extern "C" int td_run(td_ctx* c, int mode)
 	ka.counters = c->d_counters;
 	ka.ws = c->d_ws; ka.lay = c->lay;
 	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-	HIPCHK(c, td_launch_decode(&ka, c->stream));
+	if (c->spec_ready) {
+		TdSpecArgs sa{};
+		sa.logsum = ka.logsum; sa.packed = ka.packed; sa.lens = ka.lens;
+		sa.n_tiles = ka.n_tiles; sa.n_slots = ka.n_slots; sa.lmax = ka.lmax; sa.nw2 = ka.nw2; sa.nw1 = ka.nw1;
+		sa.mode = ka.mode; sa.threshold = ka.threshold; sa.minlen = ka.minlen; sa.dust = ka.dust;
+		sa.out_f = ka.out_f; sa.out_b = ka.out_b; sa.out_r = ka.out_r; sa.out_bar = ka.out_bar; sa.out_q = ka.out_q;
+		sa.out_type = ka.out_type; sa.out_barcode = ka.out_barcode; sa.out_finger = ka.out_finger;
+		sa.out_keep = ka.out_keep; sa.out_labels = ka.out_labels; sa.counters = ka.counters;
+		sa.ws = ka.ws; sa.lay = c->slay;
+		size_t sz = sizeof sa;
+		void* cfg[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &sa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END };
+		const int wpb = td_kernel_block_threads() / TD_WAVE;
+		const unsigned blocks = (unsigned)((c->n_slots + wpb - 1) / wpb);
+		HIPCHK(c, hipModuleLaunchKernel(c->spec_fn, blocks, 1, 1, (unsigned)td_kernel_block_threads(), 1, 1, 0, c->stream, nullptr, cfg));
+	} else {
+		HIPCHK(c, td_launch_decode(&ka, c->stream));
+	}
 	HIPCHK(c, hipEventRecord(c->ev1, c->stream));
 	c->ran = true;
 	c->last_ms = -1.0f;
@@ -434,7 +496,7 @@ extern "C" int td_batch_info(td_ctx* c, int64_t* n_reads, int64_t* workspace_byt
 {
 	if (!c) return TD_FAIL;
 	if (n_reads) *n_reads = c->n_reads;
-	if (workspace_bytes) *workspace_bytes = (int64_t)c->n_slots * c->lay.slot_bytes;
+	if (workspace_bytes) *workspace_bytes = (int64_t)c->n_slots * (c->spec_ready ? c->slay.slot_bytes : c->lay.slot_bytes);
 	if (wave_slots) *wave_slots = c->n_slots;
 	return TD_OK;
 }

@@ -94,3 +94,42 @@ struct TdKernelArgs {
 	uint8_t* __restrict__ ws;
 	TdWsLayout lay;
 };
+
+// ---------------------------------------------------------------------------------------------------------
+// model-specialised kernel (td_spec_kernel.inc, compiled per model with hiprtc)
+// ---------------------------------------------------------------------------------------------------------
+struct TdSpecLayout {
+	int64_t slot_bytes;
+	int64_t codes;   // u8    [lmax+2][64]
+	int64_t sb;      // f32   [S+1][lmax+2][64]
+	int64_t sf;      // f32   [S+1][lmax+2][64]
+	int64_t bw;      // f32x4 per HMM h: [lmax][ceil(ncol/2)][64] at slot offset kBwOff[h]*lmax: two columns' (M_backward, I_backward)
+	int64_t dp;      // f32   [lmax][H][64]
+	int64_t path;    // u32   [lmax][ceil(H/4)][64]   four path bytes per word
+	int64_t total;   // f32   [H][64]
+	int64_t dust;    // u8    [64][64]
+};
+
+struct TdSpecArgs {
+	const float*  __restrict__ logsum;
+	const uint32_t* __restrict__ packed;
+	const int32_t*  __restrict__ lens;
+	int32_t n_tiles, n_slots, lmax, nw2, nw1;
+	int32_t mode;
+	float   threshold;
+	int32_t minlen, dust;
+	int32_t pad0;
+	float*   __restrict__ out_f;
+	float*   __restrict__ out_b;
+	float*   __restrict__ out_r;
+	float*   __restrict__ out_bar;
+	float*   __restrict__ out_q;
+	int32_t* __restrict__ out_type;
+	int32_t* __restrict__ out_barcode;
+	int32_t* __restrict__ out_finger;
+	uint32_t* __restrict__ out_keep;
+	int8_t*  __restrict__ out_labels;
+	unsigned long long* __restrict__ counters;
+	uint8_t* __restrict__ ws;
+	TdSpecLayout lay;
+};

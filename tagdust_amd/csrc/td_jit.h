@@ -1,0 +1,12 @@
+// td_jit.h -- interface between the C-ABI layer (td_api.hip) and the model-specialised kernel builder (td_jit.hip)
+#pragma once
+#include <string>
+#include <vector>
+#include "../../include/tagdust_hip.h"
+#include "td_device.h"
+
+int td_spec_group_size(int n_hmm, int n_col);
+std::string td_spec_model_section(const td_model_desc* m);
+std::string td_spec_full_source(const td_model_desc* m);
+void td_spec_layout(TdSpecLayout& L, const td_model_desc* m, int lmax);
+int td_spec_compile(const td_model_desc* m, std::vector<char>& code, std::string& log);

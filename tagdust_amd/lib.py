@@ -18,7 +18,7 @@ NUM_COUNTERS = NUM_OUTCOME_SLOTS + NUM_BARCODE_BINS
 ABI_SYMBOLS = [
     "td_ctx_create", "td_ctx_destroy", "td_last_error", "td_logsum_table", "td_model_upload", "td_set_params",
     "td_batch_upload", "td_batch_upload_ascii", "td_run", "td_sync", "td_batch_download", "td_counts_reset",
-    "td_counts_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_batch_info",
+    "td_counts_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_batch_info", "td_set_option", "td_spec_source",
 ]
 
 RESULT_DTYPE = np.dtype([
@@ -60,6 +60,9 @@ def load_library():
     lib.td_logsum_table.restype = C.POINTER(C.c_float)
     lib.td_model_upload.argtypes = [C.c_void_p, C.POINTER(_ModelDesc)]
     lib.td_set_params.argtypes = [C.c_void_p, C.c_float, C.c_int32, C.c_int32]
+    lib.td_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+    lib.td_spec_source.argtypes = [C.POINTER(_ModelDesc), C.c_char_p, C.c_int64]
+    lib.td_spec_source.restype = C.c_int64
     lib.td_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.td_batch_upload_ascii.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.td_run.argtypes = [C.c_void_p, C.c_int]
@@ -73,6 +76,41 @@ def load_library():
     lib.td_batch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     _lib = lib
     return lib
+
+
+def make_model_desc(md):
+    """Build the C td_model_desc from a mapping of numpy tables; returns (desc, arrays to keep alive)."""
+    S, H, Cc = int(md["S"]), int(md["H"]), int(md["C"])
+    a = {
+        "n_hmm": np.ascontiguousarray(md["n_hmm"], np.int32), "n_col": np.ascontiguousarray(md["n_col"], np.int32),
+        "skip": np.ascontiguousarray(md["skip"], np.float32),
+        "seg_type": np.ascontiguousarray(md["seg_type"], np.int32).astype(np.int8),
+        "finger_len": np.where(np.asarray(md["seg_type"]) == ord("F"), np.asarray(md["seg_len"]), 0).astype(np.int32),
+        "trans": np.ascontiguousarray(md["trans"], np.float32).reshape(Cc, 9),
+        "eM": np.ascontiguousarray(md["eM"], np.float32).reshape(Cc, 5),
+        "eI": np.ascontiguousarray(md["eI"], np.float32).reshape(Cc, 5),
+        "sM": np.ascontiguousarray(md["sM"], np.float32).reshape(Cc),
+        "sI": np.ascontiguousarray(md["sI"], np.float32).reshape(Cc),
+        "label": np.ascontiguousarray(md["label"], np.int32).reshape(H),
+        "A": np.ascontiguousarray(md["A"], np.float32).reshape(H, H),
+    }
+    d = _ModelDesc()
+    d.S, d.H, d.C, d.avg_len = S, H, Cc, int(md["avg_len"])
+    for i in range(5):
+        d.bg[i] = float(np.float32(md["bg"][i]))
+    for k, v in a.items():
+        setattr(d, k, v.ctypes.data)
+    return d, a
+
+
+def spec_source(md):
+    """The HIP source of the model-specialised kernel for this model (no GPU needed)."""
+    lib = load_library()
+    d, keep = make_model_desc(md)
+    n = lib.td_spec_source(C.byref(d), None, 0)
+    buf = C.create_string_buffer(int(n) + 1)
+    lib.td_spec_source(C.byref(d), buf, int(n) + 1)
+    return buf.value.decode()
 
 
 class TagdustHip:
@@ -102,30 +140,14 @@ class TagdustHip:
         if rc != 0:
             raise TdError(self.lib.td_last_error(self.h).decode())
 
+    def set_option(self, name, value):
+        self._chk(self.lib.td_set_option(self.h, name.encode(), int(value)))
+
     def upload_model(self, md):
         """md: mapping with S,H,C,avg_len,bg,n_hmm,n_col,skip,seg_type,seg_len,trans,eM,eI,sM,sI,label,A
         (the tables of struct model_bag; same keys as the golden fixtures)."""
-        S, H, Cc = int(md["S"]), int(md["H"]), int(md["C"])
-        a = {
-            "n_hmm": np.ascontiguousarray(md["n_hmm"], np.int32), "n_col": np.ascontiguousarray(md["n_col"], np.int32),
-            "skip": np.ascontiguousarray(md["skip"], np.float32),
-            "seg_type": np.ascontiguousarray(md["seg_type"], np.int32).astype(np.int8),
-            "finger_len": np.where(np.asarray(md["seg_type"]) == ord("F"), np.asarray(md["seg_len"]), 0).astype(np.int32),
-            "trans": np.ascontiguousarray(md["trans"], np.float32).reshape(Cc, 9),
-            "eM": np.ascontiguousarray(md["eM"], np.float32).reshape(Cc, 5),
-            "eI": np.ascontiguousarray(md["eI"], np.float32).reshape(Cc, 5),
-            "sM": np.ascontiguousarray(md["sM"], np.float32).reshape(Cc),
-            "sI": np.ascontiguousarray(md["sI"], np.float32).reshape(Cc),
-            "label": np.ascontiguousarray(md["label"], np.int32).reshape(H),
-            "A": np.ascontiguousarray(md["A"], np.float32).reshape(H, H),
-        }
-        d = _ModelDesc()
-        d.S, d.H, d.C, d.avg_len = S, H, Cc, int(md["avg_len"])
-        for i in range(5):
-            d.bg[i] = float(np.float32(md["bg"][i]))
-        for k, v in a.items():
-            setattr(d, k, v.ctypes.data)
-        self._keep = a
+        d, keep = make_model_desc(md)
+        self._keep = keep
         self._chk(self.lib.td_model_upload(self.h, C.byref(d)))
 
     def set_params(self, threshold, minlen=16, dust=100):

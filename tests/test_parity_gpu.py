@@ -17,10 +17,12 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=[1, 0], ids=["specialised", "generic"])
+def ctx(request):
+    """Both device paths: the model-specialised kernel (hiprtc, default) and the generic ahead-of-time kernel."""
     from tagdust_amd import TagdustHip
     c = TagdustHip(0)
+    c.set_option("specialize", request.param)
     yield c
     c.close()
 
