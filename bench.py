@@ -80,6 +80,7 @@ def cpu_baseline(model, n_sample, seed):
     this box's host cores on a bounded sample of the same workload.  Checker/baseline only."""
     from oracle import pyoracle
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, int(os.environ.get("TD_CPU_THREADS", "16")))  # a one-GPU box's CPU share is 16 cores
     reads = synth_batch(n_sample, seed)
     offs = (np.arange(n_sample + 1, dtype=np.int64) * READ_LEN)
     om = pyoracle.OracleModel(model)
@@ -210,7 +211,7 @@ def main():
                        "wave_slots": slots, "workspace_bytes": ws_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "td_decode_kernel", "kernel_ms": k_ms,
+                         "kernel": "td_spec_kernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_read": bpr, "reads_per_launch": n,
                          "note": "algorithmic bytes are tiny (220 B/read); the kernel is VALU/LDS-issue bound and its real HBM "
                                  "traffic is the backward-row spill (see DESIGN.md)"},

@@ -63,6 +63,7 @@ struct td_ctx {
 	hipFunction_t spec_fn = nullptr;
 	std::vector<int32_t> m_n_hmm, m_n_col;
 	TdSpecLayout slay{};
+	int spec_block = 256, spec_waves_per_cu = 8;
 
 	// params
 	float threshold = 0.0f;
@@ -275,6 +276,11 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 		HIPCHK(c, hipModuleLoadData(&c->spec_mod, code.data()));
 		HIPCHK(c, hipModuleGetFunction(&c->spec_fn, c->spec_mod, "td_spec_kernel"));
 		c->spec_ready = true;
+		c->spec_block = td_spec_block_threads();
+		// resident waves per CU: two LDS tables fit a CU; a 1024-thread workgroup fills it alone
+		c->spec_waves_per_cu = (c->spec_block == 1024) ? 16 : 2 * (c->spec_block / TD_WAVE);
+		const int by_regs = 4 * td_spec_min_waves();
+		if (c->spec_waves_per_cu > by_regs) c->spec_waves_per_cu = by_regs;
 	}
 	return TD_OK;
 }
@@ -397,8 +403,8 @@ static int upload_common(td_ctx* c, const uint8_t* codes, const char* ascii, con
 		slot_bytes = c->slay.slot_bytes;
 	}
 	// wave slots: enough to fill the chip (2 workgroups of 4 waves per CU share the LDS), bounded by HBM
-	const int wpb = td_kernel_block_threads() / TD_WAVE;
-	int64_t want = (int64_t)c->n_cu * 2 * wpb;
+	const int wpb = (c->spec_ready ? c->spec_block : td_kernel_block_threads()) / TD_WAVE;
+	int64_t want = (int64_t)c->n_cu * (c->spec_ready ? c->spec_waves_per_cu : 2 * wpb);
 	if (const char* e = getenv("TD_WAVE_SLOTS")) { const long v = atol(e); if (v > 0) want = v; }
 	size_t free_b = 0, total_b = 0;
 	HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
@@ -459,9 +465,9 @@ extern "C" int td_run(td_ctx* c, int mode)
 		sa.ws = ka.ws; sa.lay = c->slay;
 		size_t sz = sizeof sa;
 		void* cfg[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &sa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END };
-		const int wpb = td_kernel_block_threads() / TD_WAVE;
+		const int wpb = c->spec_block / TD_WAVE;
 		const unsigned blocks = (unsigned)((c->n_slots + wpb - 1) / wpb);
-		HIPCHK(c, hipModuleLaunchKernel(c->spec_fn, blocks, 1, 1, (unsigned)td_kernel_block_threads(), 1, 1, 0, c->stream, nullptr, cfg));
+		HIPCHK(c, hipModuleLaunchKernel(c->spec_fn, blocks, 1, 1, (unsigned)c->spec_block, 1, 1, 0, c->stream, nullptr, cfg));
 	} else {
 		HIPCHK(c, td_launch_decode(&ka, c->stream));
 	}

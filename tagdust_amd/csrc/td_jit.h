@@ -6,6 +6,8 @@
 #include "td_device.h"
 
 int td_spec_group_size(int n_hmm, int n_col);
+int td_spec_block_threads(void);
+int td_spec_min_waves(void);
 std::string td_spec_model_section(const td_model_desc* m);
 std::string td_spec_full_source(const td_model_desc* m);
 void td_spec_layout(TdSpecLayout& L, const td_model_desc* m, int lmax);

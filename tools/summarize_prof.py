@@ -19,7 +19,7 @@ def rows(pattern):
 
 def main():
     d = sys.argv[1]
-    kname = "td_decode_kernel"
+    kname = sys.argv[2] if len(sys.argv) > 2 else "td_spec_kernel"
     res = {}
     kt = [r for r in rows(os.path.join(d, "trace", "**", "*kernel_trace.csv")) if kname in r.get("Kernel_Name", "")]
     if kt:
