@@ -110,16 +110,22 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N > 1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; TD_DIST_BACKEND=gloo lets several ranks rehearse the path on a one-GPU box
+    backend = os.environ.get("TD_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
 
-    from tagdust_amd import TagdustHip, NUM_COUNTERS
+    from tagdust_amd import TagdustHip, NUM_COUNTERS, shard
     model = load_model()
-    ctx = TagdustHip(local_rank)
+    ctx = TagdustHip(dev_index)
     ctx.upload_model(model)
     ctx.set_params(float(model["threshold"]), 16, 100)
 
@@ -146,15 +152,14 @@ def main():
 
     ctx.upload_batch(reads.reshape(-1), offs)   # resident in HBM from here on
     del reads
-    counts_t = torch.zeros(NUM_COUNTERS, dtype=torch.int64, device="cuda")
+    reduce_dev = torch.device("cuda", dev_index) if backend == "nccl" else None
+    last_counts = [None]
 
     def step():
         ctx.run()
         if world > 1:
-            # the path's only exchange: per-outcome / per-barcode counters, summed over ranks (RCCL over xGMI)
-            ctx.sync()
-            counts_t.copy_(torch.from_numpy(ctx.counts()))
-            dist.all_reduce(counts_t)
+            # the path's only exchange: the 264 per-outcome / per-barcode counters, summed over ranks (RCCL over xGMI)
+            last_counts[0] = shard.allreduce_counts(ctx.counts(), dist, device=reduce_dev)
 
     def fence():
         ctx.sync()
@@ -181,9 +186,12 @@ def main():
         ev_ms.append(ctx.last_kernel_ms())
     ctx.sync()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if last_counts[0] is not None and int(last_counts[0][:8].sum()) != n * args.steps * world:
+            raise SystemExit("bench.py: reduced outcome counters (%d) do not add up to the reads decoded (%d)"
+                             % (int(last_counts[0][:8].sum()), n * args.steps * world))
 
     if rank == 0:
         total_reads = n * args.steps * world

@@ -1,0 +1,160 @@
+/*
+ * run_phmm_shim.c -- the reference-side binding of libtagdust_hip.so: a drop-in definition of
+ *
+ *     int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, struct parameters* param,
+ *                  struct fasta* reference_fasta, int numseq, int mode);        (src/barcode_hmm.h:342)
+ *
+ * that a TagDust2 maintainer links instead of the pthread fan-out in src/barcode_hmm.c:1895-2029.  It is own
+ * code written against the reference's public structs (barcode_hmm.h, io.h, interface.h); it flattens the live
+ * struct model_bag into a td_model_desc, hands the batch to the GPU through the C-ABI (include/tagdust_hip.h) and
+ * writes the results back into struct read_info exactly where do_label_thread / do_probability_estimation leave
+ * them (mapq, labels, read_type, barcode, fingerprint, seq/qual rewritten in place, bar_prob = 100).
+ *
+ * Modes the GPU path does not cover (MODE_ARCH_COMP, -ref artifact matching, -start/-end windows) are passed to the
+ * reference's own CPU implementation, which the build recipe keeps available as ref_run_pHMM() (oracle/Makefile).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "kslib.h"
+#include "interface.h"
+#include "io.h"
+#include "barcode_hmm.h"
+#include "misc.h"
+
+#include "tagdust_hip.h"
+
+int ref_run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, struct parameters* param,
+                 struct fasta* reference_fasta, int numseq, int mode);
+
+static td_ctx* g_ctx = NULL;
+static uint64_t g_model_key = 0;
+
+/* FNV-1a over everything that defines the model, so a rebuilt model_bag (calibration, "long sequence" realloc)
+ * is re-uploaded only when its tables changed */
+static uint64_t fnv(uint64_t h, const void* p, size_t n)
+{
+	const unsigned char* b = (const unsigned char*)p;
+	for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ULL; }
+	return h;
+}
+
+static int upload_model(struct model_bag* mb, struct parameters* param)
+{
+	const int S = mb->num_models, H = mb->total_hmm_num;
+	int C = 0, j, f, g, k;
+	for (j = 0; j < S; j++) C += mb->model[j]->num_hmms * mb->model[j]->hmms[0]->num_columns;
+
+	int32_t* n_hmm = malloc(sizeof(int32_t) * S);
+	int32_t* n_col = malloc(sizeof(int32_t) * S);
+	int32_t* finger = malloc(sizeof(int32_t) * S);
+	float* skip = malloc(sizeof(float) * S);
+	int8_t* type = malloc(S);
+	float* trans = malloc(sizeof(float) * C * 9);
+	float* eM = malloc(sizeof(float) * C * 5);
+	float* eI = malloc(sizeof(float) * C * 5);
+	float* sM = malloc(sizeof(float) * C);
+	float* sI = malloc(sizeof(float) * C);
+	float* A = malloc(sizeof(float) * H * H);
+	int c = 0;
+	for (j = 0; j < S; j++) {
+		struct model* m = mb->model[j];
+		n_hmm[j] = m->num_hmms;
+		n_col[j] = m->hmms[0]->num_columns;
+		skip[j] = m->skip;
+		type[j] = param->read_structure->type[j];
+		finger[j] = (type[j] == 'F') ? (int32_t)strlen(param->read_structure->sequence_matrix[j][0]) : 0;
+		for (f = 0; f < m->num_hmms; f++) {
+			for (g = 0; g < m->hmms[f]->num_columns; g++, c++) {
+				struct hmm_column* col = m->hmms[f]->hmm_column[g];
+				for (k = 0; k < 9; k++) trans[c * 9 + k] = col->transition[k];
+				for (k = 0; k < 5; k++) { eM[c * 5 + k] = col->m_emit[k]; eI[c * 5 + k] = col->i_emit[k]; }
+				sM[c] = m->silent_to_M[f][g];
+				sI[c] = m->silent_to_I[f][g];
+			}
+		}
+	}
+	for (j = 0; j < H; j++)
+		for (k = 0; k < H; k++) A[j * H + k] = mb->transition_matrix[j][k];
+
+	td_model_desc d;
+	memset(&d, 0, sizeof d);
+	d.S = S; d.H = H; d.C = C; d.avg_len = mb->average_raw_length;
+	for (k = 0; k < 5; k++) d.bg[k] = mb->model[0]->background_nuc_frequency[k];
+	d.n_hmm = n_hmm; d.n_col = n_col; d.skip = skip; d.seg_type = type; d.finger_len = finger;
+	d.trans = trans; d.eM = eM; d.eI = eI; d.sM = sM; d.sI = sI; d.label = mb->label; d.A = A;
+
+	uint64_t key = 1469598103934665603ULL;
+	key = fnv(key, &d.S, 16); key = fnv(key, d.bg, 20);
+	key = fnv(key, n_hmm, 4 * S); key = fnv(key, n_col, 4 * S); key = fnv(key, skip, 4 * S); key = fnv(key, type, S);
+	key = fnv(key, trans, 36 * C); key = fnv(key, eM, 20 * C); key = fnv(key, eI, 20 * C);
+	key = fnv(key, sM, 4 * C); key = fnv(key, sI, 4 * C); key = fnv(key, mb->label, 4 * H); key = fnv(key, A, 4 * H * H);
+	int rc = TD_OK;
+	if (key != g_model_key) {
+		rc = td_model_upload(g_ctx, &d);
+		if (rc == TD_OK) g_model_key = key;
+	}
+	free(n_hmm); free(n_col); free(finger); free(skip); free(type);
+	free(trans); free(eM); free(eI); free(sM); free(sI); free(A);
+	return rc;
+}
+
+int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, struct parameters* param,
+             struct fasta* reference_fasta, int numseq, int mode)
+{
+	int i, k, status = kslOK;
+
+	/* not on the GPU path: architecture comparison, artifact matching, -start/-end windows */
+	if ((mode != MODE_GET_LABEL && mode != MODE_GET_PROB) || reference_fasta || param->matchstart != -1 || param->matchend != -1)
+		return ref_run_pHMM(ab, mb, ri, param, reference_fasta, numseq, mode);
+	if (numseq <= 0) return kslOK;
+
+	if (!g_ctx && td_ctx_create(0, &g_ctx) != TD_OK) {
+		fprintf(stderr, "tagdust_hip: %s\n", td_last_error(NULL));
+		return kslFAIL;
+	}
+	if (upload_model(mb, param) != TD_OK) goto ERROR;
+	if (td_set_params(g_ctx, param->confidence_threshold, param->minlen, param->dust) != TD_OK) goto ERROR;
+
+	int64_t* offs = malloc(sizeof(int64_t) * ((size_t)numseq + 1));
+	offs[0] = 0;
+	for (i = 0; i < numseq; i++) offs[i + 1] = offs[i] + ri[i]->len;
+	uint8_t* codes = malloc((size_t)offs[numseq] + 1);
+	for (i = 0; i < numseq; i++) memcpy(codes + offs[i], ri[i]->seq, (size_t)ri[i]->len);   /* already 0..4 (io.c:1759) */
+
+	td_read_result* res = malloc(sizeof(td_read_result) * (size_t)numseq);
+	int8_t* labels = malloc((size_t)offs[numseq] + (size_t)numseq);
+	uint8_t* seq_out = malloc((size_t)offs[numseq] + 1);
+	if (td_batch_upload(g_ctx, codes, offs, numseq) != TD_OK ||
+	    td_run(g_ctx, mode == MODE_GET_LABEL ? TD_MODE_GET_LABEL : TD_MODE_GET_PROB) != TD_OK ||
+	    td_batch_download(g_ctx, res, mode == MODE_GET_LABEL ? labels : NULL, mode == MODE_GET_LABEL ? seq_out : NULL) != TD_OK) {
+		status = kslFAIL;
+	} else {
+		for (i = 0; i < numseq; i++) {
+			ri[i]->mapq = res[i].mapq;
+			if (mode == MODE_GET_LABEL) {
+				const int len = ri[i]->len;
+				memcpy(ri[i]->labels, labels + offs[i] + i, (size_t)len + 1);
+				ri[i]->bar_prob = 100;                       /* barcode_hmm.c:2343 */
+				ri[i]->read_type = res[i].read_type;
+				if (res[i].barcode != -1) ri[i]->barcode = res[i].barcode;
+				if (res[i].fingerprint != -1) ri[i]->fingerprint = res[i].fingerprint;
+				for (k = 0; k < len; k++) {                 /* make_extracted_read, barcode_hmm.c:3343-3350 */
+					if (seq_out[offs[i] + k] == 65) { ri[i]->seq[k] = 65; ri[i]->qual[k] = 65; }
+				}
+				ri[i]->qual[len] = 0;                        /* barcode_hmm.c:3308 */
+			} else {
+				ri[i]->bar_prob = res[i].bar_prob;
+			}
+		}
+	}
+	free(offs); free(codes); free(res); free(labels); free(seq_out);
+	if (status != kslOK) goto ERROR;
+	return kslOK;
+ERROR:
+	fprintf(stderr, "tagdust_hip: %s\n", g_ctx ? td_last_error(g_ctx) : "no context");
+	return kslFAIL;
+}

@@ -5,3 +5,4 @@ csrc/).  This Python package is a thin ctypes mirror of that ABI for tests and b
 falls back to a CPU implementation."""
 from .lib import (TagdustHip, TdError, load_library, LIB_PATH, RESULT_DTYPE,  # noqa: F401
                   MODE_GET_LABEL, MODE_GET_PROB, NUM_COUNTERS, NUM_OUTCOME_SLOTS)
+from . import shard  # noqa: F401,E402

@@ -1,0 +1,79 @@
+"""End-to-end drop-in check on the GPU box: the reference's own CLI / FASTQ I/O / controller / threshold
+calibration with run_pHMM() bound to libtagdust_hip.so through integration/run_phmm_shim.c
+(oracle/_ref/tagdust_hip_rtest) must write byte-identical output files to the unmodified reference binary
+(oracle/_ref/tagdust_rtest), and reproduce the reference's own regression gold line for
+dev/bar_read_test.sh scenario 1.  Both binaries are built by `make -C oracle ref` in the build container."""
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, REPO
+
+pytestmark = pytest.mark.gpu
+
+RBIN = os.path.join(REPO, "oracle", "_ref")
+NEED = ["tagdust_rtest", "tagdust_hip_rtest", "simreads_rtest", "evalres_rtest"]
+# dev/barread1_tagdust_results_gold.txt:2 (the reference's regression value for scenario 1)
+SCEN1_GOLD = "tagdust\t1.0000\t0.9542\t0.9947\t0.9739\t0.0000\t8951.00\t48.00\t0.00\t1001.00"
+
+
+def _have():
+    return all(os.path.exists(os.path.join(RBIN, b)) for b in NEED)
+
+
+def _write_fastq(g, path):
+    names = bytes(g["names"]).split(b"\n")
+    offs = g["offs"]
+    with open(path, "wb") as fh:
+        for i in range(int(g["n_reads"])):
+            s = bytes(np.frombuffer(b"ACGTN", np.uint8)[g["seq"][offs[i]:offs[i + 1]]])
+            q = bytes(g["qual"][offs[i]:offs[i + 1]])
+            fh.write(b"@" + names[i] + b"\n" + s + b"\n+\n" + q + b"\n")
+
+
+def _run(binary, args, cwd):
+    p = subprocess.run([os.path.join(RBIN, binary)] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-2000:]
+    return p.stdout.decode(errors="replace")
+
+
+def _outputs(d, prefix):
+    out = {}
+    for p in sorted(glob.glob(os.path.join(d, prefix + "*"))):
+        if p.endswith("_logfile.txt"):
+            continue
+        out[os.path.basename(p)[len(prefix):]] = open(p, "rb").read()
+    return out
+
+
+@pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built (need the build container's `make -C oracle ref`)")
+@pytest.mark.parametrize("name", ["c2_b4_r", "c3_b6_s_r_p", "scen2_endloss", "umi_f_s_r"])
+def test_reference_cli_with_gpu_run_phmm_writes_identical_files(tmp_path, name):
+    g = load_golden(name)
+    fq = str(tmp_path / "in.fq")
+    _write_fastq(g, fq)
+    args = str(g["cmdline"]).split()
+    _run("tagdust_rtest", args + [fq, "-o", "cpu"], str(tmp_path))
+    log = _run("tagdust_hip_rtest", args + [fq, "-o", "gpu"], str(tmp_path))
+    cpu, gpu = _outputs(str(tmp_path), "cpu"), _outputs(str(tmp_path), "gpu")
+    assert cpu and set(cpu) == set(gpu), (sorted(cpu), sorted(gpu), log[-1500:])
+    for k in cpu:
+        assert cpu[k] == gpu[k], "output file *%s differs" % k
+
+
+@pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built")
+def test_bar_read_test_scenario1_gold(tmp_path):
+    """dev/bar_read_test.sh scenario 1 end to end with the GPU-bound binary: simreads_rtest -> tagdust -> evalres."""
+    d = str(tmp_path)
+    tags = os.path.join(REPO, "tests", "golden", "EDITTAG_6nt_ed_4_first4.txt")
+    _run("simreads_rtest", [tags, "-seed", "42", "-sim_barnum", "4", "-sim_readlen", "20", "-sim_readlen_mod", "0",
+                            "-sim_numseq", "10000", "-sim_endloss", "0", "-sim_random_frac", "0.1", "-o", "barread1.fq",
+                            "-sim_error_rate", "0.02"], d)
+    _run("tagdust_hip_rtest", ["-seed", "42", "barread1.fq", "-arch", "barread1.fq_tagdust_arch.txt", "-o", "barread1_tagdust"], d)
+    fqs = sorted(glob.glob(os.path.join(d, "barread1_tagdust*.fq")))
+    _run("evalres_rtest", ["-name", "tagdust"] + [os.path.basename(f) for f in fqs] + ["-o", "barread1_tagdust"], d)
+    lines = open(os.path.join(d, "barread1_tagdust_results.txt")).read().splitlines()
+    assert SCEN1_GOLD in [l.strip() for l in lines], lines
