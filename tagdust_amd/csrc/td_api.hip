@@ -62,6 +62,7 @@ struct td_ctx {
 	hipModule_t spec_mod = nullptr;
 	hipFunction_t spec_fn = nullptr;
 	std::vector<int32_t> m_n_hmm, m_n_col;
+	std::vector<float> m_trans;
 	TdSpecLayout slay{};
 	int spec_block = 256, spec_waves_per_cu = 8;
 
@@ -262,6 +263,7 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 	c->label.assign(m->label, m->label + m->H);
 	c->m_n_hmm.assign(m->n_hmm, m->n_hmm + m->S);
 	c->m_n_col.assign(m->n_col, m->n_col + m->S);
+	c->m_trans.assign(m->trans, m->trans + (size_t)m->C * 9);
 	c->have_model = true;
 	c->ran = false;
 	c->n_reads = 0; c->n_tiles = 0;
@@ -278,7 +280,7 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 		c->spec_ready = true;
 		c->spec_block = td_spec_block_threads();
 		// resident waves per CU: two LDS tables fit a CU; a 1024-thread workgroup fills it alone
-		c->spec_waves_per_cu = (c->spec_block == 1024) ? 16 : 2 * (c->spec_block / TD_WAVE);
+		c->spec_waves_per_cu = (c->spec_block > 512) ? c->spec_block / TD_WAVE : 2 * (c->spec_block / TD_WAVE);
 		const int by_regs = 4 * td_spec_min_waves();
 		if (c->spec_waves_per_cu > by_regs) c->spec_waves_per_cu = by_regs;
 	}
@@ -398,7 +400,7 @@ static int upload_common(td_ctx* c, const uint8_t* codes, const char* ascii, con
 	if (c->spec_ready) {
 		td_model_desc md{};
 		md.S = c->hdr.S; md.H = c->hdr.H; md.C = c->hdr.C;
-		md.n_hmm = c->m_n_hmm.data(); md.n_col = c->m_n_col.data();
+		md.n_hmm = c->m_n_hmm.data(); md.n_col = c->m_n_col.data(); md.trans = c->m_trans.data();
 		td_spec_layout(c->slay, &md, lmax);
 		slot_bytes = c->slay.slot_bytes;
 	}

@@ -103,7 +103,7 @@ struct TdSpecLayout {
 	int64_t codes;   // u8    [lmax+2][64]
 	int64_t sb;      // f32   [S+1][lmax+2][64]
 	int64_t sf;      // f32   [S+1][lmax+2][64]
-	int64_t bw;      // f32x4 per HMM h: [lmax][ceil(ncol/2)][64] at slot offset kBwOff[h]*lmax: two columns' (M_backward, I_backward)
+	int64_t bw;      // per HMM h: [lmax][stored cols][64] x (M_backward, I_backward) = 8 B; float4 pairs + float2 tail
 	int64_t dp;      // f32   [lmax][H][64]
 	int64_t path;    // u32   [lmax][ceil(H/4)][64]   four path bytes per word
 	int64_t total;   // f32   [H][64]
