@@ -36,6 +36,7 @@ extern "C" {
 /* run modes, src/barcode_hmm.h:128-132 */
 #define TD_MODE_GET_LABEL 1   /* label + Q + extraction (+ DUST)           do_label_thread            */
 #define TD_MODE_GET_PROB  4   /* Q only (threshold calibration)            do_probability_estimation  */
+#define TD_MODE_ARCH_COMP 5   /* backward() only: b_score per read         do_arch_comparison         */
 
 /* extraction outcomes, src/io.h:40-46 */
 #define TD_EXTRACT_SUCCESS                    0
@@ -121,7 +122,8 @@ int td_batch_upload(td_ctx* ctx, const uint8_t* codes, const int64_t* offs, int6
 /* Same from ASCII FASTQ sequence lines (applies the nuc_code mapping). */
 int td_batch_upload_ascii(td_ctx* ctx, const char* bases, const int64_t* offs, int64_t n_reads);
 /* Run the hot path over the resident batch on the context's stream (asynchronous; td_sync / td_batch_download
- * wait).  mode = TD_MODE_GET_LABEL or TD_MODE_GET_PROB.  Adds this batch's outcomes to the counters. */
+ * wait).  mode = TD_MODE_GET_LABEL, TD_MODE_GET_PROB or TD_MODE_ARCH_COMP (only td_read_result.b_score is then
+ * meaningful).  TD_MODE_GET_LABEL adds this batch's outcomes to the counters. */
 int td_run(td_ctx* ctx, int mode);
 int td_sync(td_ctx* ctx);
 /* Copy results of the resident batch back.  Any pointer may be NULL.

@@ -10,8 +10,8 @@
  * writes the results back into struct read_info exactly where do_label_thread / do_probability_estimation leave
  * them (mapq, labels, read_type, barcode, fingerprint, seq/qual rewritten in place, bar_prob = 100).
  *
- * Modes the GPU path does not cover (MODE_ARCH_COMP, -ref artifact matching, -start/-end windows) are passed to the
- * reference's own CPU implementation, which the build recipe keeps available as ref_run_pHMM() (oracle/Makefile).
+ * What the GPU path does not cover (the dead training modes, -ref artifact matching, -start/-end windows) is passed to
+ * the reference's own CPU implementation, which the build recipe keeps available as ref_run_pHMM() (oracle/Makefile).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -42,7 +42,7 @@ static uint64_t fnv(uint64_t h, const void* p, size_t n)
 	return h;
 }
 
-static int upload_model(struct model_bag* mb, struct parameters* param)
+static int upload_model(struct model_bag* mb, struct parameters* param, int with_types)
 {
 	const int S = mb->num_models, H = mb->total_hmm_num;
 	int C = 0, j, f, g, k;
@@ -65,7 +65,9 @@ static int upload_model(struct model_bag* mb, struct parameters* param)
 		n_hmm[j] = m->num_hmms;
 		n_col[j] = m->hmms[0]->num_columns;
 		skip[j] = m->skip;
-		type[j] = param->read_structure->type[j];
+		/* segment types only matter for extraction; the candidate models of an architecture comparison are scored
+		 * by backward() alone and param->read_structure does not describe them */
+		type[j] = with_types ? param->read_structure->type[j] : 'R';
 		finger[j] = (type[j] == 'F') ? (int32_t)strlen(param->read_structure->sequence_matrix[j][0]) : 0;
 		for (f = 0; f < m->num_hmms; f++) {
 			for (g = 0; g < m->hmms[f]->num_columns; g++, c++) {
@@ -102,13 +104,58 @@ static int upload_model(struct model_bag* mb, struct parameters* param)
 	return rc;
 }
 
+/* MODE_ARCH_COMP (do_arch_comparison, barcode_hmm.c:2111-2148 + the merge at :1995-2016): every candidate model
+ * scores every read with backward(); arch_posterior[j] is the float sum of b_score, accumulated per thread range
+ * in read order and then over threads -- the summation order (hence the float result) depends on -t, so it is
+ * reproduced here on the host from the per-read b_scores the GPU returns.  The many short-lived candidate models
+ * use the generic kernel (no per-model compile). */
+static int arch_comparison(struct arch_bag* ab, struct read_info** ri, struct parameters* param, int numseq)
+{
+	int i, j, t, rc = kslOK;
+	const int T = param->num_threads > 0 ? param->num_threads : 1;
+	const int interval = (int)(numseq / T);
+	int64_t* offs = malloc(sizeof(int64_t) * ((size_t)numseq + 1));
+	offs[0] = 0;
+	for (i = 0; i < numseq; i++) offs[i + 1] = offs[i] + ri[i]->len;
+	uint8_t* codes = malloc((size_t)offs[numseq] + 1);
+	for (i = 0; i < numseq; i++) memcpy(codes + offs[i], ri[i]->seq, (size_t)ri[i]->len);
+	td_read_result* res = malloc(sizeof(td_read_result) * (size_t)numseq);
+
+	if (td_set_option(g_ctx, "specialize", 0) != TD_OK) rc = kslFAIL;
+	for (j = 0; j < ab->num_arch && rc == kslOK; j++) {
+		g_model_key = 0;
+		if (upload_model(ab->archs[j], param, 0) != TD_OK || td_batch_upload(g_ctx, codes, offs, numseq) != TD_OK ||
+		    td_run(g_ctx, TD_MODE_ARCH_COMP) != TD_OK || td_batch_download(g_ctx, res, NULL, NULL) != TD_OK) {
+			rc = kslFAIL;
+			break;
+		}
+		for (t = 0; t < T; t++) {
+			const int start = t * interval, end = (t == T - 1) ? numseq : (t + 1) * interval;
+			float partial = prob2scaledprob(1.0);            /* thread_data[t].ab->arch_posterior[i], :1938 */
+			for (i = start; i < end; i++) partial += res[i].b_score;
+			ab->arch_posterior[j] += partial;                /* :2003 */
+		}
+	}
+	g_model_key = 0;
+	if (rc == kslOK) {                                       /* :2009-2016 */
+		float sum = ab->arch_posterior[0];
+		for (i = 1; i < ab->num_arch; i++) sum = logsum(sum, ab->arch_posterior[i]);
+		for (i = 0; i < ab->num_arch; i++) ab->arch_posterior[i] = ab->arch_posterior[i] - sum;
+	} else {
+		fprintf(stderr, "tagdust_hip: %s\n", td_last_error(g_ctx));
+	}
+	free(offs); free(codes); free(res);
+	return rc;
+}
+
 int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, struct parameters* param,
              struct fasta* reference_fasta, int numseq, int mode)
 {
 	int i, k, status = kslOK;
 
-	/* not on the GPU path: architecture comparison, artifact matching, -start/-end windows */
-	if ((mode != MODE_GET_LABEL && mode != MODE_GET_PROB) || reference_fasta || param->matchstart != -1 || param->matchend != -1)
+	/* not on the GPU path: training modes, artifact matching, -start/-end windows */
+	if ((mode != MODE_GET_LABEL && mode != MODE_GET_PROB && mode != MODE_ARCH_COMP) || (mode == MODE_ARCH_COMP && !ab) ||
+	    reference_fasta || param->matchstart != -1 || param->matchend != -1)
 		return ref_run_pHMM(ab, mb, ri, param, reference_fasta, numseq, mode);
 	if (numseq <= 0) return kslOK;
 
@@ -116,7 +163,9 @@ int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, s
 		fprintf(stderr, "tagdust_hip: %s\n", td_last_error(NULL));
 		return kslFAIL;
 	}
-	if (upload_model(mb, param) != TD_OK) goto ERROR;
+	if (mode == MODE_ARCH_COMP) return arch_comparison(ab, ri, param, numseq);
+	if (td_set_option(g_ctx, "specialize", 1) != TD_OK) goto ERROR;
+	if (upload_model(mb, param, 1) != TD_OK) goto ERROR;
 	if (td_set_params(g_ctx, param->confidence_threshold, param->minlen, param->dust) != TD_OK) goto ERROR;
 
 	int64_t* offs = malloc(sizeof(int64_t) * ((size_t)numseq + 1));

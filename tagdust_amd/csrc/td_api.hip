@@ -291,9 +291,7 @@ extern "C" int td_set_option(td_ctx* c, const char* name, int32_t value)
 {
 	if (!c || !name) return TD_FAIL;
 	if (!strcmp(name, "specialize")) {
-		if (c->have_model && (value != 0) != (c->specialize != 0))
-			return fail(c, "td_set_option: set \"specialize\" before td_model_upload");
-		c->specialize = value != 0;
+		c->specialize = value != 0; // takes effect at the next td_model_upload
 		return TD_OK;
 	}
 	return fail(c, "td_set_option: unknown option %s", name);
@@ -438,7 +436,7 @@ extern "C" int td_run(td_ctx* c, int mode)
 {
 	if (!c) return TD_FAIL;
 	if (!c->have_model) return fail(c, "td_run: no model uploaded");
-	if (mode != TD_MODE_GET_LABEL && mode != TD_MODE_GET_PROB) return fail(c, "td_run: unsupported mode %d", mode);
+	if (mode != TD_MODE_GET_LABEL && mode != TD_MODE_GET_PROB && mode != TD_MODE_ARCH_COMP) return fail(c, "td_run: unsupported mode %d", mode);
 	HIPCHK(c, hipSetDevice(c->device));
 	if (c->n_tiles == 0) { c->ran = true; c->last_ms = 0.0f; return TD_OK; }
 	const OutLayout ol = out_layout(c->n_tiles, c->lmax, c->nw1);

@@ -32,6 +32,7 @@
 // run modes / outcomes (mirrors include/tagdust_hip.h)
 #define MODE_GET_LABEL 1
 #define MODE_GET_PROB 4
+#define MODE_ARCH_COMP 5
 #define OUT_SUCCESS 0
 #define OUT_ARCH_MISMATCH 1
 #define OUT_TOO_SHORT 2
@@ -519,6 +520,10 @@ __global__ __launch_bounds__(TD_BLOCK, 2) void td_decode_kernel(const TdKernelAr
 					})
 			}
 			b_score = (len >= 1) ? SB[0 * rowlen + 1 * TD_WAVE + lane] : NEG_INF; // :3610
+		}
+		if (ka.mode == MODE_ARCH_COMP) { // do_arch_comparison, barcode_hmm.c:2111-2148: backward only
+			ka.out_b[rid] = b_score;
+			continue;
 		}
 		// A read without any valid path has b_score = -inf; the reference then indexes its table with NaN
 		// and crashes.  Here such a read is reported as an architecture mismatch with Q = 0.

@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(HERE, "libtagdust_hip.so")
 
 MODE_GET_LABEL = 1
 MODE_GET_PROB = 4
+MODE_ARCH_COMP = 5
 NUM_OUTCOME_SLOTS = 8
 NUM_BARCODE_BINS = 256
 NUM_COUNTERS = NUM_OUTCOME_SLOTS + NUM_BARCODE_BINS

@@ -77,3 +77,23 @@ def test_bar_read_test_scenario1_gold(tmp_path):
     _run("evalres_rtest", ["-name", "tagdust"] + [os.path.basename(f) for f in fqs] + ["-o", "barread1_tagdust"], d)
     lines = open(os.path.join(d, "barread1_tagdust_results.txt")).read().splitlines()
     assert SCEN1_GOLD in [l.strip() for l in lines], lines
+
+
+@pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built")
+def test_architecture_selection_through_gpu(tmp_path):
+    """-arch file with several candidate architectures: test_architectures() -> run_pHMM(MODE_ARCH_COMP) on the GPU must pick
+    the same architecture (same posteriors in the log) and write the same files as the CPU reference."""
+    g = load_golden("c2_b4_r")
+    fq = str(tmp_path / "in.fq")
+    _write_fastq(g, fq)
+    arch = str(tmp_path / "arch.txt")
+    real = " ".join(str(g["cmdline"]).split()[2:])
+    open(arch, "w").write("tagdust -1 R:N\n" + "tagdust " + real + "\n" + "tagdust -1 B:GGGG,CCCC -2 R:N\n")
+    cpu_log = _run("tagdust_rtest", ["-seed", "42", "-t", "3", "-arch", arch, fq, "-o", "cpu"], str(tmp_path))
+    gpu_log = _run("tagdust_hip_rtest", ["-seed", "42", "-t", "3", "-arch", arch, fq, "-o", "gpu"], str(tmp_path))
+    pick = lambda log: [l.split("]", 1)[-1].strip() for l in log.splitlines() if "Confidence" in l or "Using:" in l or "-1 " in l]
+    assert pick(cpu_log) == pick(gpu_log) and pick(cpu_log)
+    cpu, gpu = _outputs(str(tmp_path), "cpu"), _outputs(str(tmp_path), "gpu")
+    assert cpu and set(cpu) == set(gpu)
+    for k in cpu:
+        assert cpu[k] == gpu[k], "output file *%s differs" % k

@@ -126,3 +126,16 @@ def test_long_segment_fallback_matches_oracle(ctx):
     assert np.array_equal(labels, olab)
     assert np.array_equal(res["read_type"], ores["read_type"])
     assert np.array_equal(seq_after, oseq)
+
+
+@pytest.mark.parametrize("name", ["c2_b4_r", "scen2_endloss", "o_b_s_r"])
+def test_backward_only_mode(ctx, name):
+    """TD_MODE_ARCH_COMP (do_arch_comparison, barcode_hmm.c:2111-2148): backward() alone, b_score bit-exact."""
+    from tagdust_amd import MODE_ARCH_COMP
+    g = load_golden(name)
+    ctx.upload_model(g)
+    ctx.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+    ctx.upload_batch(g["seq"], g["offs"])
+    ctx.run(MODE_ARCH_COMP)
+    res, _, _ = ctx.download(labels=False, seq=False)
+    assert np.array_equal(_bits(res["b_score"]), _bits(g["b_score"]))
