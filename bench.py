@@ -35,7 +35,59 @@ WORKLOAD = ("config3: 150bp reads, arch -1 B:%s -2 S:%s -3 R:N -4 P:%s (BASELINE
 _CODE = {"A": 0, "C": 1, "G": 2, "T": 3}
 
 
-def synth_batch(n, seed, read_len=READ_LEN, random_frac=0.1, sub=0.02):
+# other BASELINE.json configurations, selectable with --workload for development measurements (the contract's
+# bench line is always the default, config 3)
+WORKLOADS = {
+    "c3": dict(fixture="c3_b6_s_r_p", read_len=150, barcodes=BARCODES, umi=0, spacer=SPACER, adapter=ADAPTER, name=WORKLOAD),
+    "c2": dict(fixture="c2_b4_r", read_len=100, barcodes=["TGCT", "AAAA", "AACC", "AAGG", "AATT", "ACAC", "ACCA", "ACGT"],
+               umi=0, spacer="", adapter="", name="config2: 100bp reads, arch -1 B:<8 of EDITTAG_4nt_ed_2> -2 R:N (BASELINE.json configs[1])"),
+    "c5": dict(fixture="c5_b96_f_r_p", read_len=150, barcodes=None, umi=8, spacer="", adapter=ADAPTER,
+               name="config5: 150bp reads, arch -1 B:<96 of EDITTAG_6nt_ed_3> -2 F:NNNNNNNN -3 R:N -4 P:AGATCGGAAGAGC (BASELINE.json configs[4])"),
+}
+_ACTIVE = dict(WORKLOADS["c3"])
+
+
+def synth_batch(n, seed, read_len=None, random_frac=0.1, sub=0.02):
+    if _ACTIVE["fixture"] != "c3_b6_s_r_p":
+        return synth_batch_generic(n, seed, _ACTIVE, random_frac, sub)
+    return synth_batch_c3(n, seed, READ_LEN, random_frac, sub)
+
+
+def synth_batch_generic(n, seed, w, random_frac=0.1, sub=0.02):
+    """[barcode][UMI][spacer] + uniform insert + 3' adapter prefix, 2 % substitutions, 10 % random reads."""
+    rng = np.random.default_rng(seed)
+    L = w["read_len"]
+    bars = w["barcodes"]
+    if bars is None:
+        z = np.load(os.path.join(REPO, "tests", "golden", w["fixture"] + ".npz"))
+        bars = str(z["seg_seqs"]).split(";")[0].split(",")[:-1]
+    x = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    bar = np.array([[_CODE[c] for c in b] for b in bars], np.uint8)
+    head = bar[rng.integers(0, len(bars), n)]
+    if w["umi"]:
+        head = np.concatenate([head, rng.integers(0, 4, size=(n, w["umi"]), dtype=np.uint8)], axis=1)
+    if w["spacer"]:
+        head = np.concatenate([head, np.tile(np.array([_CODE[c] for c in w["spacer"]], np.uint8), (n, 1))], axis=1)
+    y = x.copy()
+    y[:, :head.shape[1]] = head
+    structured = np.zeros((n, L), bool)
+    structured[:, :bar.shape[1]] = True
+    if w["adapter"]:
+        ad = np.array([_CODE[c] for c in w["adapter"]], np.uint8)
+        keep = rng.integers(0, len(ad) + 1, n)
+        pos = np.arange(L)[None, :]
+        start = (L - keep)[:, None]
+        in_ad = pos >= start
+        y = np.where(in_ad, ad[np.clip(pos - start, 0, len(ad) - 1)], y)
+        structured |= in_ad
+    mut = structured & (rng.random((n, L)) < sub)
+    y = np.where(mut, rng.integers(0, 4, size=(n, L), dtype=np.uint8), y)
+    is_random = rng.random(n) < random_frac
+    y[is_random] = x[is_random]
+    return np.ascontiguousarray(y)
+
+
+def synth_batch_c3(n, seed, read_len=READ_LEN, random_frac=0.1, sub=0.02):
     """simulate_reads-style synthetic reads for an architecture simreads cannot emit (S: segment):
     [barcode][GTA] + uniform insert + a prefix of the 3' adapter, 2 % substitutions, 10 % fully random
     reads.  Returns base codes (n, read_len) uint8."""
@@ -71,7 +123,7 @@ def algorithmic_bytes_per_read(L):
 def load_model():
     """Model tables for the workload architecture, as built by the reference's init_model_bag() and
     committed as a fixture (tests/golden/c3_b6_s_r_p.npz); threshold = the reference's calibrated one."""
-    z = np.load(os.path.join(REPO, "tests", "golden", "c3_b6_s_r_p.npz"))
+    z = np.load(os.path.join(REPO, "tests", "golden", _ACTIVE["fixture"] + ".npz"))
     return {k: z[k] for k in z.files}
 
 
@@ -100,7 +152,12 @@ def main():
     ap.add_argument("--reads", type=int, default=1 << 20, help="reads per step per GPU")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="reads in the CPU baseline sample (0 = skip)")
     ap.add_argument("--check", type=int, default=2048, help="reads verified against the oracle before timing (0 = skip)")
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS), help="development only; the bench line is c3")
+    ap.add_argument("--specialize", type=int, default=1, help="0 = generic ahead-of-time kernel")
     args = ap.parse_args()
+    _ACTIVE.update(WORKLOADS[args.workload])
+    global READ_LEN
+    READ_LEN = _ACTIVE["read_len"]
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -126,6 +183,7 @@ def main():
     from tagdust_amd import TagdustHip, NUM_COUNTERS, shard
     model = load_model()
     ctx = TagdustHip(dev_index)
+    ctx.set_option("specialize", args.specialize)
     ctx.upload_model(model)
     ctx.set_params(float(model["threshold"]), 16, 100)
 
@@ -214,12 +272,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD, "read_len": READ_LEN, "reads_per_step_per_gpu": n,
+            "config": {"workload": _ACTIVE["name"], "read_len": READ_LEN, "reads_per_step_per_gpu": n,
                        "parallelism": "static shard of reads over %d GPU(s), counters all-reduced per step" % world,
                        "wave_slots": slots, "workspace_bytes": ws_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "td_spec_kernel", "kernel_ms": k_ms,
+                         "kernel": "td_spec_kernel" if args.specialize else "td_decode_kernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_read": bpr, "reads_per_launch": n,
                          "note": "algorithmic bytes are tiny (220 B/read); the kernel is VALU/LDS-issue bound and its real HBM "
                                  "traffic is the backward-row spill (see DESIGN.md)"},

@@ -1,0 +1,437 @@
+// td_model.cpp -- host-side model construction (declared in include/tagdust_model.h): own restatement of how the
+// reference turns a read architecture + sequence statistics into the tables of struct model_bag.  Pure host code.
+//
+// The float/double mixing below is deliberate and follows the reference expression by expression: prob2scaledprob()
+// takes a *float* parameter (src/misc.c:85), so every double-valued argument expression is narrowed to float before the
+// (double) log(); sequencer_error_rate / indel_frequency are floats (src/interface.h:119-120) that become doubles only
+// when passed to set_hmm_transition_parameters().
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/tagdust_model.h"
+
+namespace {
+
+const double INV_SQRT_2PI = 0.3989422804014327; // src/misc.h:75
+
+float p2sp(float p) { return (p == 0.0) ? -INFINITY : (float)log((double)p); }   // prob2scaledprob, misc.c:85-92
+float sp2p(float p) { return (p == -INFINITY) ? 0.0f : (float)exp((double)p); }  // scaledprob2prob, misc.c:98-105
+
+float logsum_f(float a, float b) // logsum, misc.c:72-78
+{
+	const float* T = td_logsum_table();
+	const float mx = (a > b) ? a : b;
+	const float mn = (a < b) ? a : b;
+	if (mn == -INFINITY || (mx - mn) >= 15.7f) return mx;
+	return mx + T[(int)((mx - mn) * 1000.0f)];
+}
+
+double gaussian_pdf(double x, double m, double s) // misc.c:375-379
+{
+	const double a = (x - m) / s;
+	return INV_SQRT_2PI / s * exp(-0.5 * a * a);
+}
+
+int nuc_code(char ch) // init_nuc_code, nuc_code.c:46-74
+{
+	switch (ch) {
+	case 'A': case 'a': return 0;
+	case 'C': case 'c': return 1;
+	case 'G': case 'g': return 2;
+	case 'T': case 't': case 'U': case 'u': return 3;
+	case '.': return 5;
+	default: return 4;
+	}
+}
+
+struct Col { float t[9]; float eM[5]; float eI[5]; };
+struct Seg {
+	int n_hmm = 0, n_col = 0;
+	float skip = -INFINITY;
+	std::vector<Col> cols;      // [n_hmm * n_col]
+	std::vector<float> sM, sI;  // [n_hmm * n_col]
+	Col& col(int f, int g) { return cols[(size_t)f * n_col + g]; }
+};
+
+enum { MM = 0, MI, MD, II, IM, DD, DM, MSKIP, ISKIP };
+
+// set_hmm_transition_parameters(), barcode_hmm.c:1710-1881, for HMM f of a segment
+void set_transitions(Seg& sg, int f, int len, double base_error, double indel_freq, double mean, double stdev)
+{
+	double sum_prob = 0.0;
+	if (mean > 0.0 && stdev > 0.0)
+		for (int i = 0; i <= len; i++) sum_prob += gaussian_pdf(i, mean, stdev);
+	auto mskip = [&](double at) -> float {
+		if (mean == -1.0 && stdev == -1.0) return p2sp(0.0);
+		if (mean > -1.0 && stdev == -1.0) return p2sp(mean / (float)(len - 1));
+		return p2sp(gaussian_pdf(at, mean, stdev) / sum_prob);
+	};
+	auto dead = [&](Col& c) {
+		c.t[MM] = p2sp(0.0f); c.t[MI] = p2sp(0.0f); c.t[MD] = p2sp(0.0f); c.t[MSKIP] = p2sp(1.0);
+		c.t[II] = p2sp(0.00); c.t[IM] = p2sp(0.0); c.t[ISKIP] = p2sp(0.0f);
+		c.t[DD] = p2sp(0.0f); c.t[DM] = p2sp(0.0f);
+	};
+	if (len == 1) {
+		dead(sg.col(f, 0));
+		return;
+	}
+	// columns 0 .. len-2 share one shape; what differs is the MI/MD split, DD/DM and the position fed to the Gaussian
+	auto live = [&](Col& c, double at, double mi_scale, double md_scale, float dd, float dm) {
+		c.t[MSKIP] = mskip(at);
+		const float x = p2sp(1.0 - sp2p(c.t[MSKIP]));
+		c.t[MM] = p2sp(1.0 - base_error * indel_freq) + x;
+		c.t[MI] = p2sp(base_error * indel_freq * mi_scale) + x;
+		c.t[MD] = p2sp(base_error * indel_freq * md_scale) + x;
+		c.t[II] = p2sp(1.0 - 0.999);
+		c.t[IM] = p2sp(0.999);
+		c.t[ISKIP] = p2sp(0.0f);
+		c.t[DD] = dd;
+		c.t[DM] = dm;
+	};
+	if (len == 2) {
+		// :1744-1783 -- "base_error * indel_freq" without a 0.5 split, MD = log(0) + X
+		Col& c = sg.col(f, 0);
+		c.t[MSKIP] = mskip(0);
+		const float x = p2sp(1.0 - sp2p(c.t[MSKIP]));
+		c.t[MM] = p2sp(1.0 - base_error * indel_freq) + x;
+		c.t[MI] = p2sp(base_error * indel_freq) + x;
+		c.t[MD] = p2sp(base_error * indel_freq * 0.0) + x;
+		c.t[II] = p2sp(1.0 - 0.999); c.t[IM] = p2sp(0.999); c.t[ISKIP] = p2sp(0.0f);
+		c.t[DD] = p2sp(0.0); c.t[DM] = p2sp(0.0);
+		dead(sg.col(f, 1));
+		return;
+	}
+	live(sg.col(f, 0), 0, 0.5, 0.5, p2sp(0.0), p2sp(0.0));                                        // :1785-1808
+	for (int i = 1; i < len - 2; i++) live(sg.col(f, i), i, 0.5, 0.5, p2sp(1.0 - 0.999), p2sp(0.999)); // :1811-1836
+	live(sg.col(f, len - 2), len - 1.0, 1.0, 0.0, p2sp(0.0), p2sp(1.0));                          // :1839-1862
+	dead(sg.col(f, len - 1));                                                                      // :1866-1878
+}
+
+// init_model_according_to_read_structure(), barcode_hmm.c:4689-5084
+void init_segment(Seg& sg, const td_arch* a, int key, float base_error, float indel_freq, const double* background, int assumed_length)
+{
+	const int n = a->n_seq[key], len = a->seq_len[key];
+	sg.n_hmm = n; sg.n_col = len;
+	sg.cols.assign((size_t)n * len, Col());
+	sg.sM.assign((size_t)n * len, p2sp(0.0f));
+	sg.sI.assign((size_t)n * len, p2sp(0.0f));
+	sg.skip = p2sp(0.0f);
+	for (int i = 0; i < n; i++) {
+		const char* tmpl = a->seqs[key][i];
+		for (int j = 0; j < len; j++) {
+			Col& c = sg.col(i, j);
+			int cur = nuc_code(tmpl[j]);
+			if (cur < 4) {
+				for (int x = 0; x < 4; x++) {
+					c.eM[x] = (x == cur) ? p2sp(1.0 - sp2p(background[4]) - base_error * (1.0 - indel_freq))
+					                     : p2sp(base_error * (1.0 - indel_freq) / 3.0);
+					c.eI[x] = background[x];
+				}
+				c.eM[4] = background[4];
+				c.eI[4] = background[4];
+			} else if (cur == 4) {
+				for (int x = 0; x < 5; x++) { c.eM[x] = background[x]; c.eI[x] = background[x]; }
+			} else { // '.'
+				for (int x = 0; x < 5; x++) { c.eM[x] = (x == 4) ? p2sp(1.0) : p2sp(0.0); c.eI[x] = background[x]; }
+			}
+		}
+		set_transitions(sg, i, len, base_error, indel_freq, -1.0, -1.0);
+	}
+	const char type = a->type[key];
+	if (type == 'B' || type == 'F' || type == 'S') { // :4897-4921
+		for (int i = 0; i < n; i++) sg.sM[(size_t)i * len] = p2sp(1.0 / (float)n);
+	}
+	if (type == 'P') { // :4923-4942
+		for (int i = 0; i < n; i++) {
+			sg.sM[(size_t)i * len] = p2sp(1.0 / (float)n) + p2sp(1.0 - 0.01);
+			for (int j = 0; j < len; j++) {
+				Col& c = sg.col(i, j);
+				c.t[MM] = p2sp(1.0 - base_error * indel_freq) + p2sp(0.99f);
+				c.t[MI] = p2sp(base_error * indel_freq) + p2sp(0.5) + p2sp(0.99f);
+				c.t[MD] = p2sp(base_error * indel_freq) + p2sp(0.5) + p2sp(0.99f);
+				c.t[MSKIP] = p2sp(0.01f);
+				c.t[II] = p2sp(1.0 - 0.999) + p2sp(0.99f);
+				c.t[IM] = p2sp(0.999) + p2sp(0.99f);
+				c.t[ISKIP] = p2sp(0.01f);
+			}
+		}
+		sg.skip = p2sp(0.01);
+	}
+	if (type == 'O' || type == 'G') { // :4946-5040: insert-only segments
+		for (int i = 0; i < n; i++) {
+			sg.sI[(size_t)i * len] = (type == 'O') ? p2sp(1.0 / (float)n) + p2sp(0.5) : p2sp(0.8935878);
+			for (int j = 0; j < len; j++) {
+				Col& c = sg.col(i, j);
+				for (int x = 0; x < 5; x++) { c.eI[x] = c.eM[x]; c.eM[x] = p2sp(0.0); }
+			}
+		}
+		sg.skip = (type == 'O') ? p2sp(0.5) : p2sp(1.0 - 0.8935878);
+		Col& c = sg.col(0, 0);
+		c.t[MM] = p2sp(0.0); c.t[MI] = p2sp(0.0); c.t[MD] = p2sp(0.0);
+		c.t[IM] = p2sp(0.0); c.t[DD] = p2sp(0.0); c.t[DM] = p2sp(0.0);
+		if (type == 'O') {
+			c.t[MSKIP] = p2sp(0.0);
+			c.t[II] = p2sp(1.0 - 1.0 / (float)(len + 1));
+			c.t[ISKIP] = p2sp(1.0 / (float)(len + 1));
+		} else {
+			c.t[II] = p2sp(0.195); // MSKIP / ISKIP keep their default values (:5018-5028)
+		}
+	}
+	if (type == 'R') { // :5042-5082
+		for (int i = 0; i < n; i++) sg.sI[(size_t)i * len] = p2sp(1.0 / (float)n);
+		Col& c = sg.col(0, 0);
+		for (int x = 0; x < 5; x++) { c.eM[x] = background[x]; c.eI[x] = background[x]; }
+		c.t[MM] = p2sp(0.0); c.t[MI] = p2sp(0.0); c.t[MD] = p2sp(0.0); c.t[MSKIP] = p2sp(0.0);
+		c.t[II] = p2sp(1.0 - 1.0 / (float)assumed_length);
+		c.t[IM] = p2sp(0.0);
+		c.t[ISKIP] = p2sp(1.0 / (float)assumed_length);
+		c.t[DD] = p2sp(0.0); c.t[DM] = p2sp(0.0);
+		sg.skip = p2sp(0.0);
+	}
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// assign_segment_sequences(), interface.c:489-598
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int td_arch_parse(const char* const* segments, int32_t n_segments, td_arch** out)
+{
+	if (!segments || !out || n_segments < 1 || n_segments > TD_MAX_SEGMENTS) return TD_FAIL;
+	td_arch* a = (td_arch*)calloc(1, sizeof(td_arch));
+	if (!a) return TD_FAIL;
+	a->n_segments = n_segments;
+	for (int j = 0; j < n_segments; j++) {
+		const char* s = segments[j];
+		if (!s || !strchr("RGOPSFB", s[0]) || !s[0] || s[1] != ':') { td_arch_free(a); return TD_FAIL; }
+		std::vector<std::vector<char>> seqs(1);
+		if (s[0] == 'R') {
+			seqs[0] = { 'N' };
+		} else {
+			for (const char* p = s + 2; *p; p++) {
+				if (*p == ',') seqs.emplace_back();
+				else seqs.back().push_back(*p);
+			}
+		}
+		if (s[0] == 'B' || s[0] == 'S') seqs.emplace_back(seqs[0].size(), 'N'); // the all-N decoy, :563-581
+		a->type[j] = s[0];
+		a->n_seq[j] = (int32_t)seqs.size();
+		a->seq_len[j] = (int32_t)seqs[0].size();
+		if (a->seq_len[j] < 1) { td_arch_free(a); return TD_FAIL; }
+		a->seqs[j] = (char**)calloc(seqs.size(), sizeof(char*));
+		for (size_t f = 0; f < seqs.size(); f++) {
+			// all HMMs of a segment have hmms[0]'s column count (barcode_hmm.c:5822); shorter ones are padded with N
+			a->seqs[j][f] = (char*)calloc((size_t)a->seq_len[j] + 1, 1);
+			for (int g = 0; g < a->seq_len[j]; g++) a->seqs[j][f][g] = g < (int)seqs[f].size() ? seqs[f][g] : 'N';
+		}
+	}
+	*out = a;
+	return TD_OK;
+}
+
+extern "C" void td_arch_free(td_arch* a)
+{
+	if (!a) return;
+	for (int j = 0; j < a->n_segments; j++) {
+		if (!a->seqs[j]) continue;
+		for (int f = 0; f < a->n_seq[j]; f++) free(a->seqs[j][f]);
+		free(a->seqs[j]);
+	}
+	free(a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// get_sequence_stats(), io.c:52-300
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int td_sequence_stats(const td_arch* a, const uint8_t* codes, const int64_t* offs, int64_t n_reads, td_seq_stats* ssi)
+{
+	if (!a || !codes || !offs || !ssi || n_reads < 0) return TD_FAIL;
+	memset(ssi, 0, sizeof *ssi);
+	for (int i = 0; i < 5; i++) ssi->background[i] = 1.0;
+	int five_len = 0, three_len = 0;
+	std::vector<int> five, three;
+	const int last = a->n_segments - 1;
+	if (a->type[0] == 'P') {
+		five_len = a->seq_len[0];
+		ssi->expected_5_len = five_len;
+		for (int i = 0; i < five_len; i++) five.push_back(nuc_code(a->seqs[0][0][i]));
+	}
+	if (a->type[last] == 'P') {
+		three_len = a->seq_len[last];
+		ssi->expected_3_len = three_len;
+		for (int i = 0; i < three_len; i++) three.push_back(nuc_code(a->seqs[last][0][i]));
+	}
+	double five_s0 = 0, five_s1 = 0, five_s2 = 0, three_s0 = 0, three_s1 = 0, three_s2 = 0;
+	// the reference reads batches of num_query = 1 000 001 reads and stops once more than 1 000 000 were seen (:184)
+	const int64_t total_read = n_reads < 1000001 ? n_reads : 1000001;
+	for (int64_t r = 0; r < total_read; r++) {
+		const uint8_t* seq = codes + offs[r];
+		const int len = (int)(offs[r + 1] - offs[r]);
+		// seq[len] is the loader's 0 terminator (io.c:1759); anything further out is outside the reference's domain
+		auto at = [&](int k) -> int { return (k >= 0 && k < len) ? seq[k] : (k == len ? 0 : -1); };
+		if (len > ssi->max_seq_len) ssi->max_seq_len = len;
+		ssi->average_length += len;
+		for (int j = 0; j < len; j++) ssi->background[seq[j] > 4 ? 4 : seq[j]] += 1.0f;
+		if (five_len) { // longest exact match of a linker suffix against the read start, > 3 nt (:141-156)
+			for (int j = 0; j <= five_len; j++) {
+				int c;
+				for (c = 0; c < five_len - j; c++)
+					if (at(c) != five[j + c]) break;
+				if (c == five_len - j && c > 3) {
+					five_s0++; five_s1 += five_len - j; five_s2 += (five_len - j) * (five_len - j);
+					break;
+				}
+			}
+		}
+		if (three_len) { // longest exact match of a linker prefix against the read end (:158-173)
+			for (int j = 0; j <= three_len; j++) {
+				int c;
+				for (c = 0; c < three_len - j; c++)
+					if (at(len - (three_len - j - c)) != three[c]) break;
+				if (c == three_len - j && c > 3) {
+					three_s0++; three_s1 += three_len - j; three_s2 += (three_len - j) * (three_len - j);
+					break;
+				}
+			}
+		}
+	}
+	if (five_len) {
+		if (five_s0 <= 1) { ssi->mean_5_len = ssi->expected_5_len; ssi->stdev_5_len = 1.0; }
+		else {
+			ssi->mean_5_len = five_s1 / five_s0;
+			ssi->stdev_5_len = sqrt((five_s0 * five_s2 - pow(five_s1, 2.0)) / (five_s0 * (five_s0 - 1.0)));
+			if (!ssi->stdev_5_len) ssi->stdev_5_len = 10000.0;
+		}
+	} else { ssi->mean_5_len = -1.0; ssi->stdev_5_len = -1.0; }
+	if (three_len) {
+		if (three_s0 <= 1) { ssi->mean_3_len = ssi->expected_3_len; ssi->stdev_3_len = 1.0; }
+		else {
+			ssi->mean_3_len = three_s1 / three_s0;
+			ssi->stdev_3_len = sqrt((three_s0 * three_s2 - pow(three_s1, 2.0)) / (three_s0 * (three_s0 - 1.0)));
+			if (!ssi->stdev_3_len) ssi->stdev_3_len = 10000.0;
+		}
+	} else { ssi->mean_3_len = -1.0; ssi->stdev_3_len = -1.0; }
+	ssi->average_length = (int)floor((double)ssi->average_length / (double)total_read + 0.5); // :261
+	double sum = 0.0;
+	for (int i = 0; i < 5; i++) sum += ssi->background[i];
+	for (int i = 0; i < 5; i++) ssi->background[i] = p2sp(ssi->background[i] / sum); // :268-270 (float-valued)
+	return TD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// init_model_bag(), barcode_hmm.c:5760-6011
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int td_model_build(const td_arch* a, const td_seq_stats* ssi, float e, float d, td_model_tables** out)
+{
+	if (!a || !ssi || !out) return TD_FAIL;
+	const int S = a->n_segments;
+	// expected read length, :5788-5810
+	int read_length = (int)ssi->average_length;
+	for (int i = 0; i < S; i++) {
+		if (a->type[i] == 'G') read_length = read_length - 2;
+		else if (a->type[i] == 'R') { }
+		else if (a->type[i] == 'P') read_length = read_length - a->seq_len[i] / 2;
+		else read_length = read_length - a->seq_len[i];
+	}
+	if (read_length < 20) read_length = 20;
+
+	std::vector<Seg> seg(S);
+	int H = 0, C = 0;
+	for (int i = 0; i < S; i++) {
+		int segment_length = 0;
+		if (a->type[i] == 'G') segment_length = 2;
+		if (a->type[i] == 'R') segment_length = read_length;
+		init_segment(seg[i], a, i, e, d, ssi->background, segment_length);
+		H += seg[i].n_hmm;
+		C += seg[i].n_hmm * seg[i].n_col;
+	}
+	if (H > TD_MAX_HMMS) return TD_FAIL;
+
+	if (ssi->expected_5_len) { // 5' partial segment, :5841-5904
+		Seg& m = seg[0];
+		double sum_prob = p2sp(0.0);
+		for (int i = 0; i < m.n_hmm; i++) {
+			for (int j = 0; j < ssi->expected_5_len; j++) {
+				m.sM[(size_t)i * m.n_col + j] = p2sp(1.0 / (float)m.n_hmm) +
+				    p2sp(gaussian_pdf(j, ssi->expected_5_len - ssi->mean_5_len, ssi->stdev_5_len));
+				sum_prob = logsum_f(sum_prob, m.sM[(size_t)i * m.n_col + j]);
+			}
+			set_transitions(m, i, (int)ssi->expected_5_len, e, d, -1.0, -1.0);
+		}
+		m.skip = p2sp(gaussian_pdf(ssi->expected_5_len, ssi->mean_5_len - ssi->expected_5_len, ssi->stdev_5_len));
+		sum_prob = logsum_f(sum_prob, m.skip);
+		for (int i = 0; i < m.n_hmm; i++)
+			for (int j = 0; j < ssi->expected_5_len; j++)
+				m.sM[(size_t)i * m.n_col + j] = m.sM[(size_t)i * m.n_col + j] - sum_prob;
+		m.skip = m.skip - sum_prob;
+	}
+	if (ssi->expected_3_len) { // 3' partial segment, :5907-5920
+		double sum_prob = 0;
+		for (int i = 0; i < ssi->expected_3_len; i++) sum_prob += gaussian_pdf(i, ssi->mean_3_len, ssi->stdev_3_len);
+		Seg& m = seg[S - 1];
+		m.skip = p2sp(gaussian_pdf(0, ssi->mean_3_len, ssi->stdev_3_len) / sum_prob);
+		for (int i = 0; i < m.n_hmm; i++) {
+			m.sM[(size_t)i * m.n_col] = p2sp(1.0 / (float)m.n_hmm) + p2sp(1.0 - gaussian_pdf(0, ssi->mean_3_len, ssi->stdev_3_len) / sum_prob);
+			set_transitions(m, i, (int)ssi->expected_3_len, e, d, ssi->mean_3_len, ssi->stdev_3_len);
+		}
+	}
+	for (int c = 1; c < S - 1; c++) { // internal partial segments, :5922-5932
+		if (a->type[c] == 'P')
+			for (int i = 0; i < seg[c].n_hmm; i++) set_transitions(seg[c], i, seg[c].n_col, e, d, 0.1, -1.0);
+	}
+
+	// flatten
+	const size_t bytes = sizeof(int32_t) * (3 * (size_t)S + H) + sizeof(float) * ((size_t)S + 21 * (size_t)C + (size_t)H * H) + S + 64;
+	td_model_tables* t = (td_model_tables*)calloc(1, sizeof(td_model_tables));
+	uint8_t* mem = (uint8_t*)calloc(1, bytes);
+	if (!t || !mem) { free(t); free(mem); return TD_FAIL; }
+	t->storage = mem;
+	auto take = [&](size_t n) { void* p = mem; mem += (n + 7) & ~(size_t)7; return p; };
+	int32_t* n_hmm = (int32_t*)take(4 * S); int32_t* n_col = (int32_t*)take(4 * S); int32_t* finger = (int32_t*)take(4 * S);
+	float* skip = (float*)take(4 * S); int8_t* type = (int8_t*)take(S);
+	float* trans = (float*)take(36 * (size_t)C); float* eM = (float*)take(20 * (size_t)C); float* eI = (float*)take(20 * (size_t)C);
+	float* sM = (float*)take(4 * (size_t)C); float* sI = (float*)take(4 * (size_t)C);
+	int32_t* label = (int32_t*)take(4 * (size_t)H); float* A = (float*)take(4 * (size_t)H * H);
+	int c = 0, h = 0;
+	for (int j = 0; j < S; j++) {
+		n_hmm[j] = seg[j].n_hmm; n_col[j] = seg[j].n_col; skip[j] = seg[j].skip; type[j] = a->type[j];
+		finger[j] = (a->type[j] == 'F') ? a->seq_len[j] : 0;
+		for (int f = 0; f < seg[j].n_hmm; f++, h++) {
+			label[h] = (f << 16) | j;                                          // :5954-5965
+			if (seg[j].skip != p2sp(0.0)) label[h] |= (int32_t)0x80000000;
+			for (int g = 0; g < seg[j].n_col; g++, c++) {
+				const Col& q = seg[j].col(f, g);
+				memcpy(trans + 9 * (size_t)c, q.t, 36); memcpy(eM + 5 * (size_t)c, q.eM, 20); memcpy(eI + 5 * (size_t)c, q.eI, 20);
+				sM[c] = seg[j].sM[(size_t)f * seg[j].n_col + g]; sI[c] = seg[j].sI[(size_t)f * seg[j].n_col + g];
+			}
+		}
+	}
+	for (int i = 0; i < H; i++) { // label transition matrix, :5978-6006
+		int open = 1;
+		for (int j = i + 1; j < H; j++) {
+			float v = 0;
+			if ((label[i] & 0xFFFF) + 1 == (label[j] & 0xFFFF)) v = 1;
+			if (((label[i] & 0xFFFF) < (label[j] & 0xFFFF)) && open) v = 1;
+			if (!(label[j] & 0x80000000)) open = 0;
+			A[(size_t)i * H + j] = v;
+		}
+		A[(size_t)i * H + i] = 1;
+	}
+	td_model_desc& m = t->desc;
+	m.S = S; m.H = H; m.C = C; m.avg_len = (int32_t)ssi->average_length;
+	for (int i = 0; i < 5; i++) m.bg[i] = (float)ssi->background[i];
+	m.n_hmm = n_hmm; m.n_col = n_col; m.skip = skip; m.seg_type = type; m.finger_len = finger;
+	m.trans = trans; m.eM = eM; m.eI = eI; m.sM = sM; m.sI = sI; m.label = label; m.A = A;
+	*out = t;
+	return TD_OK;
+}
+
+extern "C" void td_model_tables_free(td_model_tables* t)
+{
+	if (!t) return;
+	free(t->storage);
+	free(t);
+}

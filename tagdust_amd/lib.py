@@ -21,6 +21,7 @@ ABI_SYMBOLS = [
     "td_batch_upload", "td_batch_upload_ascii", "td_run", "td_sync", "td_batch_download", "td_counts_reset",
     "td_counts_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_batch_info", "td_set_option", "td_spec_source",
 ]
+MODEL_ABI_SYMBOLS = ["td_arch_parse", "td_arch_free", "td_sequence_stats", "td_model_build", "td_model_tables_free"]
 
 RESULT_DTYPE = np.dtype([
     ("f_score", "<f4"), ("b_score", "<f4"), ("r_score", "<f4"), ("bar_prob", "<f4"), ("mapq", "<f4"),
@@ -30,6 +31,12 @@ RESULT_DTYPE = np.dtype([
 
 class TdError(RuntimeError):
     pass
+
+
+class _SeqStats(C.Structure):
+    _fields_ = [("background", C.c_double * 5), ("expected_5_len", C.c_double), ("expected_3_len", C.c_double),
+                ("mean_5_len", C.c_double), ("stdev_5_len", C.c_double), ("mean_3_len", C.c_double),
+                ("stdev_3_len", C.c_double), ("average_length", C.c_double), ("max_seq_len", C.c_int32)]
 
 
 class _ModelDesc(C.Structure):
@@ -75,6 +82,13 @@ def load_library():
     lib.td_counts_device_ptr.restype = C.c_void_p
     lib.td_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.td_batch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    lib.td_arch_parse.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_void_p)]
+    lib.td_arch_free.argtypes = [C.c_void_p]
+    lib.td_arch_free.restype = None
+    lib.td_sequence_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(_SeqStats)]
+    lib.td_model_build.argtypes = [C.c_void_p, C.POINTER(_SeqStats), C.c_float, C.c_float, C.POINTER(C.c_void_p)]
+    lib.td_model_tables_free.argtypes = [C.c_void_p]
+    lib.td_model_tables_free.restype = None
     _lib = lib
     return lib
 
@@ -102,6 +116,55 @@ def make_model_desc(md):
     for k, v in a.items():
         setattr(d, k, v.ctypes.data)
     return d, a
+
+
+def build_model(segments, codes, offs, e=0.05, d=0.1, stats_override=None):
+    """Host model construction through the C library (include/tagdust_model.h; no GPU needed):
+    td_arch_parse -> td_sequence_stats -> td_model_build.  segments: ["B:ACGT,...", "R:N", ...].
+    Returns (model mapping with the golden-fixture keys, stats dict)."""
+    lib = load_library()
+    arr = (C.c_char_p * len(segments))(*[s.encode() for s in segments])
+    arch = C.c_void_p()
+    if lib.td_arch_parse(arr, len(segments), C.byref(arch)) != 0:
+        raise TdError("td_arch_parse failed for %r" % (segments,))
+    try:
+        codes = np.ascontiguousarray(codes, np.uint8)
+        offs = np.ascontiguousarray(offs, np.int64)
+        st = _SeqStats()
+        if lib.td_sequence_stats(arch, codes.ctypes.data, offs.ctypes.data, len(offs) - 1, C.byref(st)) != 0:
+            raise TdError("td_sequence_stats failed")
+        if stats_override:
+            for k, v in stats_override.items():
+                setattr(st, k, v)
+        tab = C.c_void_p()
+        if lib.td_model_build(arch, C.byref(st), float(e), float(d), C.byref(tab)) != 0:
+            raise TdError("td_model_build failed")
+        try:
+            desc = C.cast(tab, C.POINTER(_ModelDesc)).contents
+            S, H, Cc = desc.S, desc.H, desc.C
+
+            def arr_of(ptr, ctype, n, dtype):
+                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).astype(dtype).copy()
+            md = {
+                "S": S, "H": H, "C": Cc, "avg_len": desc.avg_len, "bg": np.array(list(desc.bg), np.float32),
+                "n_hmm": arr_of(desc.n_hmm, C.c_int32, S, np.int32), "n_col": arr_of(desc.n_col, C.c_int32, S, np.int32),
+                "skip": arr_of(desc.skip, C.c_float, S, np.float32),
+                "seg_type": arr_of(desc.seg_type, C.c_int8, S, np.int32),
+                "trans": arr_of(desc.trans, C.c_float, Cc * 9, np.float32).reshape(Cc, 9),
+                "eM": arr_of(desc.eM, C.c_float, Cc * 5, np.float32).reshape(Cc, 5),
+                "eI": arr_of(desc.eI, C.c_float, Cc * 5, np.float32).reshape(Cc, 5),
+                "sM": arr_of(desc.sM, C.c_float, Cc, np.float32), "sI": arr_of(desc.sI, C.c_float, Cc, np.float32),
+                "label": arr_of(desc.label, C.c_int32, H, np.int32),
+                "A": arr_of(desc.A, C.c_float, H * H, np.float32).reshape(H, H),
+            }
+            fl = arr_of(desc.finger_len, C.c_int32, S, np.int32)
+            md["seg_len"] = np.where(md["seg_type"] == ord("F"), fl, md["n_col"]).astype(np.int32)
+            stats = {k: (list(getattr(st, k)) if k == "background" else getattr(st, k)) for k, _ in _SeqStats._fields_}
+            return md, stats
+        finally:
+            lib.td_model_tables_free(tab)
+    finally:
+        lib.td_arch_free(arch)
 
 
 def spec_source(md):

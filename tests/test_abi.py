@@ -21,11 +21,14 @@ def library():
 
 
 def test_header_symbols_all_exported(library):
-    hdr = open(os.path.join(REPO, "include", "tagdust_hip.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(td_[a-z_0-9]+)\s*\(", hdr))
+    declared = set()
+    for name, want in (("tagdust_hip.h", tdlib.ABI_SYMBOLS), ("tagdust_model.h", tdlib.MODEL_ABI_SYMBOLS)):
+        hdr = open(os.path.join(REPO, "include", name)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        found = set(re.findall(r"\b(td_[a-z_0-9]+)\s*\(", hdr))
+        assert found == set(want), name
+        declared |= found
     assert declared, "no prototypes parsed"
-    assert declared == set(tdlib.ABI_SYMBOLS)
     for name in sorted(declared):
         assert hasattr(library, name), name
 
