@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/tagdust_hip.h"
@@ -75,6 +76,7 @@ struct td_ctx {
 	int32_t n_tiles = 0, lmax = 0, nw2 = 0, nw1 = 0;
 	std::vector<int64_t> offs;
 	std::vector<uint8_t> codes_host; // kept for td_batch_download(seq_out)
+	std::vector<int64_t> pos_of;     // pos_of[i] = position of read i in the length-sorted device order
 	uint32_t* d_packed = nullptr; size_t cap_packed = 0;
 	int32_t* d_lens = nullptr;    size_t cap_lens = 0;
 	uint8_t* d_out = nullptr;     size_t cap_out = 0;   // all per-read outputs in one allocation
@@ -367,17 +369,47 @@ static int upload_common(td_ctx* c, const uint8_t* codes, const char* ascii, con
 		asc2code['T'] = asc2code['t'] = 3; asc2code['U'] = asc2code['u'] = 3;
 		asc_ready = true;
 	}
-	for (int64_t i = 0; i < n; i++) {
-		const int64_t tile = i / TD_WAVE; const int lane = (int)(i % TD_WAVE);
-		const int l = (int)(offs[i + 1] - offs[i]);
-		lens[(size_t)i] = l;
-		uint32_t* pk = packed.data() + tile * tile_words;
-		for (int k = 0; k < l; k++) {
-			uint8_t cd = codes ? codes[offs[i] + k] : asc2code[(uint8_t)ascii[offs[i] + k]];
-			if (cd > 4) cd = 4;
-			c->codes_host[(size_t)(offs[i] + k)] = cd;
-			if (cd == 4) pk[(nw2 + (k >> 5)) * TD_WAVE + lane] |= 1u << (k & 31);
-			else pk[(k >> 4) * TD_WAVE + lane] |= (uint32_t)cd << (2 * (k & 15));
+	// Reads are laid out on the device sorted by length (stable counting sort), so that the 64 reads of a tile have
+	// (nearly) the same length and no lane idles through another read's extra positions; results are un-permuted on
+	// download.  Per-read results do not depend on the order (every read is decoded independently).
+	c->pos_of.assign((size_t)n, 0);
+	{
+		std::vector<int64_t> start((size_t)lmax + 2, 0);
+		for (int64_t i = 0; i < n; i++) start[(size_t)(offs[i + 1] - offs[i]) + 1]++;
+		for (int l = 0; l <= lmax; l++) start[(size_t)l + 1] += start[(size_t)l];
+		for (int64_t i = 0; i < n; i++) c->pos_of[(size_t)i] = start[(size_t)(offs[i + 1] - offs[i])]++;
+	}
+	// every read owns its (tile, lane) words, so reads can be packed by several host threads without synchronisation
+	auto pack_range = [&](int64_t lo, int64_t hi) {
+		for (int64_t i = lo; i < hi; i++) {
+			const int64_t k = c->pos_of[(size_t)i];
+			const int64_t tile = k / TD_WAVE; const int lane = (int)(k % TD_WAVE);
+			const int l = (int)(offs[i + 1] - offs[i]);
+			lens[(size_t)k] = l;
+			uint32_t* pk = packed.data() + tile * tile_words;
+			for (int kk = 0; kk < l; kk++) {
+				uint8_t cd = codes ? codes[offs[i] + kk] : asc2code[(uint8_t)ascii[offs[i] + kk]];
+				if (cd > 4) cd = 4;
+				c->codes_host[(size_t)(offs[i] + kk)] = cd;
+				if (cd == 4) pk[(nw2 + (kk >> 5)) * TD_WAVE + lane] |= 1u << (kk & 31);
+				else pk[(kk >> 4) * TD_WAVE + lane] |= (uint32_t)cd << (2 * (kk & 15));
+			}
+		}
+	};
+	{
+		int nt = (int)std::thread::hardware_concurrency();
+		if (const char* e = getenv("TD_HOST_THREADS")) nt = atoi(e);
+		if (nt > 16) nt = 16;
+		if (nt < 1 || n < 65536) nt = 1;
+		if (nt == 1) pack_range(0, n);
+		else {
+			std::vector<std::thread> th;
+			const int64_t per = (n + nt - 1) / nt;
+			for (int t = 0; t < nt; t++) {
+				const int64_t lo = t * per, hi = lo + per < n ? lo + per : n;
+				if (lo < hi) th.emplace_back(pack_range, lo, hi);
+			}
+			for (auto& t : th) t.join();
 		}
 	}
 	if (ensure(c, &c->d_packed, &c->cap_packed, packed.size() * 4) != TD_OK) return TD_FAIL;
@@ -525,8 +557,9 @@ extern "C" int td_batch_download(td_ctx* c, td_read_result* res, int8_t* labels,
 		const float* q = (const float*)(h.data() + ol.q); const int32_t* ty = (const int32_t*)(h.data() + ol.type);
 		const int32_t* bc = (const int32_t*)(h.data() + ol.barcode); const int32_t* fg = (const int32_t*)(h.data() + ol.finger);
 		for (int64_t i = 0; i < n; i++) {
-			res[i].f_score = f[i]; res[i].b_score = b[i]; res[i].r_score = r[i]; res[i].bar_prob = bar[i];
-			res[i].mapq = q[i]; res[i].read_type = ty[i]; res[i].barcode = bc[i]; res[i].fingerprint = fg[i];
+			const int64_t k = c->pos_of[(size_t)i];
+			res[i].f_score = f[k]; res[i].b_score = b[k]; res[i].r_score = r[k]; res[i].bar_prob = bar[k];
+			res[i].mapq = q[k]; res[i].read_type = ty[k]; res[i].barcode = bc[k]; res[i].fingerprint = fg[k];
 		}
 		(void)np;
 	}
@@ -535,7 +568,8 @@ extern "C" int td_batch_download(td_ctx* c, td_read_result* res, int8_t* labels,
 		std::vector<int8_t> h(bytes);
 		HIPCHK(c, hipMemcpy(h.data(), c->d_out + ol.labels, bytes, hipMemcpyDeviceToHost));
 		for (int64_t i = 0; i < n; i++) {
-			const int64_t tile = i / TD_WAVE; const int lane = (int)(i % TD_WAVE);
+			const int64_t k = c->pos_of[(size_t)i];
+			const int64_t tile = k / TD_WAVE; const int lane = (int)(k % TD_WAVE);
 			const int l = (int)(c->offs[i + 1] - c->offs[i]);
 			const int8_t* src = h.data() + tile * (int64_t)(c->lmax + 1) * TD_WAVE;
 			int8_t* dst = labels + c->offs[i] + i;
@@ -547,7 +581,8 @@ extern "C" int td_batch_download(td_ctx* c, td_read_result* res, int8_t* labels,
 		std::vector<uint32_t> h(words);
 		HIPCHK(c, hipMemcpy(h.data(), c->d_out + ol.keep, words * 4, hipMemcpyDeviceToHost));
 		for (int64_t i = 0; i < n; i++) {
-			const int64_t tile = i / TD_WAVE; const int lane = (int)(i % TD_WAVE);
+			const int64_t k = c->pos_of[(size_t)i];
+			const int64_t tile = k / TD_WAVE; const int lane = (int)(k % TD_WAVE);
 			const int l = (int)(c->offs[i + 1] - c->offs[i]);
 			const uint32_t* kw = h.data() + tile * (int64_t)c->nw1 * TD_WAVE;
 			for (int k = 0; k < l; k++) {

@@ -139,3 +139,42 @@ def test_backward_only_mode(ctx, name):
     ctx.run(MODE_ARCH_COMP)
     res, _, _ = ctx.download(labels=False, seq=False)
     assert np.array_equal(_bits(res["b_score"]), _bits(g["b_score"]))
+
+
+def test_ascii_upload_and_large_ragged_batch(ctx):
+    """td_batch_upload_ascii (nuc_code mapping incl. lower case, U, IUPAC -> N) on a ragged batch large enough to use the
+    threaded host packing and several tiles per wave; HIP == oracle."""
+    from oracle import pyoracle
+    g = load_golden("c2_b4_r")
+    rng = np.random.RandomState(99)
+    n = 70000
+    lens = rng.randint(20, 101, n)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    codes = rng.randint(0, 4, int(offs[-1])).astype(np.uint8)
+    codes[rng.random_sample(len(codes)) < 0.003] = 4
+    src = g["offs"]
+    for i in range(0, n, 2):   # plant real reads (prefixes) so that barcodes are found
+        k = i % int(g["n_reads"])
+        s_ = g["seq"][src[k]:src[k + 1]][:lens[i]]
+        codes[offs[i]:offs[i] + len(s_)] = s_
+    alphabet = np.frombuffer(b"ACGTN", np.uint8)
+    ascii_ = alphabet[codes].copy()
+    lower = rng.random_sample(len(ascii_)) < 0.1
+    ascii_[lower] = np.frombuffer(b"acgtn", np.uint8)[codes[lower]]
+    tu = (codes == 3) & (rng.random_sample(len(codes)) < 0.05)
+    ascii_[tu] = ord("U")
+    amb = (codes == 4) & (rng.random_sample(len(codes)) < 0.5)
+    ascii_[amb] = ord("R")
+    ctx.upload_model(g)
+    ctx.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+    ctx.upload_batch_ascii(ascii_, offs)
+    ctx.run()
+    res, labels, seq_after = ctx.download()
+    ores, olab, oseq = pyoracle.label_batch(pyoracle.OracleModel(g), codes, offs, float(g["threshold"]), int(g["minlen"]), int(g["dust"]), 16)
+    for k in ("b_score", "f_score", "r_score", "bar_prob"):
+        assert np.array_equal(_bits(res[k]), _bits(ores[k])), k
+    assert np.array_equal(labels, olab)
+    assert np.allclose(res["mapq"], ores["Q"], rtol=0, atol=Q_TOL)
+    for k in ("read_type", "barcode", "fingerprint"):
+        assert np.array_equal(res[k], ores[k]), k
+    assert np.array_equal(seq_after, oseq)
