@@ -178,3 +178,26 @@ def test_ascii_upload_and_large_ragged_batch(ctx):
     for k in ("read_type", "barcode", "fingerprint"):
         assert np.array_equal(res[k], ores[k]), k
     assert np.array_equal(seq_after, oseq)
+
+
+@pytest.mark.parametrize("name", ["c2_b4_r", "c3_b6_s_r_p", "casava_index", "scen1_b_r", "o_b_s_r"])
+def test_runtime_hmm_loop_path(name, monkeypatch):
+    """The specialised kernel's run-time HMM loop (normally only for segments with >= 16 HMMs, e.g. 96 barcodes) forced
+    onto small barcode segments: same bits as the reference."""
+    from tagdust_amd import TagdustHip, lib as tdlib
+    monkeypatch.setenv("TD_SPEC_RT_MIN", "3")
+    g = load_golden(name)
+    assert "kRt[%d] = {0" % int(g["S"]) not in tdlib.spec_source(g) or name == "o_b_s_r"
+    c = TagdustHip(0)
+    try:
+        res, labels, seq_after = _run(c, g)
+    finally:
+        c.close()
+    for k in ("b_score", "f_score", "r_score"):
+        assert np.array_equal(_bits(res[k]), _bits(g[k])), k
+    assert np.array_equal(_bits(res["bar_prob"]), _bits(g["bar_prob"].astype(np.float32)))
+    assert np.array_equal(labels, g["labels"])
+    assert np.allclose(res["mapq"], g["mapq"], rtol=0, atol=Q_TOL)
+    for k in ("read_type", "barcode", "fingerprint"):
+        assert np.array_equal(res[k], g[k]), k
+    assert np.array_equal(seq_after, g["seq_after"])
