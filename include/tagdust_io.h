@@ -1,0 +1,49 @@
+/*
+ * tagdust_io.h -- FASTQ/FASTA ingest and demultiplexed FASTQ egress around the decode path (part of
+ * libtagdust_hip.so, plain C, host only).  SURVEY.md 8(f2): at GPU decode rates the reference's fgets()/fprintf()
+ * loops are the end-to-end limiter, so these are chunk-parallel and buffered.  They mirror
+ *
+ *   read_fasta_fastq()   src/io.c:1684-1815   (record state machine, name up to the first control character,
+ *                                              base codes through nuc_code)            -> td_reads_parse
+ *   print_all()          src/io.c:757-1016    (file set, ";FP:%d" / ";RQ:%0.2f" header tags, one record per run of
+ *                                              kept bases, unextracted reads to "_un")  -> td_writer_*
+ * for one input file.
+ */
+#ifndef TAGDUST_IO_H
+#define TAGDUST_IO_H
+
+#include <stdint.h>
+#include "tagdust_hip.h"
+#include "tagdust_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct td_reads {
+	int64_t  n_reads;
+	const char* text;      /* the caller's buffer; names and qualities are referenced in place */
+	int64_t* name_off;     /* [n] offset of the name (after '@' / '>') in text */
+	int32_t* name_len;     /* [n] */
+	int64_t* qual_off;     /* [n] offset of the quality string, -1 for FASTA records */
+	int64_t* offs;         /* [n+1] read boundaries in codes (ready for td_batch_upload) */
+	uint8_t* codes;        /* base codes 0..4 ('.' -> 5 like the reference) */
+} td_reads;
+
+/* Parse a whole FASTQ/FASTA text held in memory with n_threads host threads (<= 0: pick).  */
+int  td_reads_parse(const char* text, int64_t len, int32_t n_threads, td_reads** out);
+void td_reads_free(td_reads* reads);
+
+typedef struct td_writer td_writer;
+/* Open print_all()'s file set for one input file: "<prefix>_BC_<barcode>.fq" per barcode + "<prefix>_un.fq", or
+ * "<prefix>.fq" + "<prefix>_un.fq" without a barcode segment ("_READ<k>" suffixes when the architecture has several
+ * R segments).  Existing files are overwritten. */
+int  td_writer_open(const char* out_prefix, const td_arch* arch, td_writer** out);
+/* Append one decoded batch: res / seq_out exactly as td_batch_download returns them. */
+int  td_writer_write(td_writer* w, const td_reads* reads, const td_read_result* res, const uint8_t* seq_out);
+int  td_writer_close(td_writer* w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

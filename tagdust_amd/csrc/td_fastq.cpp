@@ -1,0 +1,232 @@
+// td_fastq.cpp -- chunk-parallel FASTQ/FASTA parsing and buffered demultiplexed FASTQ writing (include/tagdust_io.h).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/tagdust_io.h"
+
+namespace {
+
+inline bool is_cntrl(unsigned char ch) { return ch < 32 || ch == 127; } // iscntrl() in the C locale
+
+struct Code {
+	uint8_t t[256];
+	Code()
+	{ // init_nuc_code(), src/nuc_code.c:46-74
+		for (int k = 0; k < 256; k++) t[k] = 4;
+		t['.'] = 5;
+		t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3; t['U'] = t['u'] = 3;
+	}
+};
+const Code kCode;
+
+struct Rec { int64_t name_off; int32_t name_len; int64_t seq_off; int32_t seq_len; int64_t qual_off; };
+
+// read_fasta_fastq()'s line state machine (io.c:1697-1799) over text[lo, hi); lo must be the start of a line
+void parse_range(const char* text, int64_t lo, int64_t hi, std::vector<Rec>& out)
+{
+	bool set = false, seq_p = false;
+	int64_t p = lo;
+	while (p < hi) {
+		const char* nl = (const char*)memchr(text + p, '\n', (size_t)(hi - p));
+		const int64_t e = nl ? (nl - text) : hi; // line = [p, e)
+		const char first = (p < e) ? text[p] : '\n';
+		auto field_len = [&](int64_t from) { int64_t q = from; while (q < e && !is_cntrl((unsigned char)text[q])) q++; return (int32_t)(q - from); };
+		if ((first == '@' || first == '>') && !set) {
+			Rec r; r.name_off = p + 1; r.name_len = field_len(p + 1); r.seq_off = -1; r.seq_len = 0; r.qual_off = -1;
+			out.push_back(r);
+			seq_p = true; set = true;
+		} else if (first == '+' && !set) {
+			seq_p = false; set = true;
+		} else {
+			if (set && !out.empty()) {
+				if (seq_p) { out.back().seq_off = p; out.back().seq_len = field_len(p); }
+				else out.back().qual_off = p;
+			}
+			set = false;
+		}
+		p = e + 1;
+	}
+}
+
+} // namespace
+
+extern "C" int td_reads_parse(const char* text, int64_t len, int32_t n_threads, td_reads** out)
+{
+	if (!text || len < 0 || !out) return TD_FAIL;
+	if (n_threads <= 0) { n_threads = (int)std::thread::hardware_concurrency(); if (n_threads > 16) n_threads = 16; }
+	if (n_threads < 1 || len < (1 << 22)) n_threads = 1;
+	// chunk boundaries at record starts.  FASTQ: a line starting with '@' whose line after next starts with '+' (a quality
+	// line may start with '@', but then the line after next is a sequence, which cannot start with '+').  FASTA (text
+	// starts with '>'): any line starting with '>'.  The first chunk starts at 0.
+	const bool fasta = len > 0 && text[0] == '>';
+	std::vector<int64_t> cut(1, 0);
+	for (int t = 1; t < n_threads; t++) {
+		int64_t p = len / n_threads * t;
+		while (p < len && text[p] != '\n') p++;
+		p++;
+		bool found = false;
+		for (int tries = 0; tries < 64 && p < len; tries++) {
+			const char* nl1 = (const char*)memchr(text + p, '\n', (size_t)(len - p));
+			if (!nl1) break;
+			if (fasta && text[p] == '>') { found = true; break; }
+			if (!fasta && text[p] == '@') {
+				const char* nl2 = (const char*)memchr(nl1 + 1, '\n', (size_t)(len - (nl1 + 1 - text)));
+				if (nl2 && nl2 + 1 < text + len && nl2[1] == '+') { found = true; break; }
+			}
+			p = nl1 - text + 1;
+		}
+		if (found && p > cut.back()) cut.push_back(p);
+	}
+	cut.push_back(len);
+	const int nchunk = (int)cut.size() - 1;
+	std::vector<std::vector<Rec>> recs((size_t)nchunk);
+	{
+		std::vector<std::thread> th;
+		for (int k = 1; k < nchunk; k++) th.emplace_back(parse_range, text, cut[(size_t)k], cut[(size_t)k + 1], std::ref(recs[(size_t)k]));
+		parse_range(text, cut[0], cut[1], recs[0]);
+		for (auto& t : th) t.join();
+	}
+	int64_t n = 0;
+	for (auto& v : recs) n += (int64_t)v.size();
+	td_reads* r = (td_reads*)calloc(1, sizeof(td_reads));
+	if (!r) return TD_FAIL;
+	r->n_reads = n; r->text = text;
+	r->name_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n + 1)); r->name_len = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+	r->qual_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n + 1)); r->offs = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n + 1));
+	if (!r->name_off || !r->name_len || !r->qual_off || !r->offs) { td_reads_free(r); return TD_FAIL; }
+	std::vector<int64_t> seq_off((size_t)n);
+	int64_t i = 0, total = 0;
+	r->offs[0] = 0;
+	for (auto& v : recs)
+		for (const Rec& q : v) {
+			r->name_off[i] = q.name_off; r->name_len[i] = q.name_len; r->qual_off[i] = q.qual_off;
+			seq_off[(size_t)i] = q.seq_off;
+			total += q.seq_off >= 0 ? q.seq_len : 0;
+			r->offs[++i] = total;
+		}
+	r->codes = (uint8_t*)malloc((size_t)total + 1);
+	if (!r->codes) { td_reads_free(r); return TD_FAIL; }
+	auto encode = [&](int64_t lo, int64_t hi) {
+		for (int64_t k = lo; k < hi; k++) {
+			const int64_t so = seq_off[(size_t)k];
+			uint8_t* dst = r->codes + r->offs[k];
+			const int64_t l = r->offs[k + 1] - r->offs[k];
+			for (int64_t j = 0; j < l; j++) dst[j] = kCode.t[(unsigned char)text[so + j]];
+		}
+	};
+	if (n_threads == 1 || n < 65536) encode(0, n);
+	else {
+		std::vector<std::thread> th;
+		const int64_t per = (n + n_threads - 1) / n_threads;
+		for (int t = 0; t < n_threads; t++) { const int64_t lo = t * per, hi = lo + per < n ? lo + per : n; if (lo < hi) th.emplace_back(encode, lo, hi); }
+		for (auto& t : th) t.join();
+	}
+	*out = r;
+	return TD_OK;
+}
+
+extern "C" void td_reads_free(td_reads* r)
+{
+	if (!r) return;
+	free(r->name_off); free(r->name_len); free(r->qual_off); free(r->offs); free(r->codes);
+	free(r);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// print_all(), io.c:757-1016, for one input file
+// ---------------------------------------------------------------------------------------------------------
+struct td_writer {
+	std::vector<FILE*> files;
+	std::vector<std::string> buf;
+	int num_alternatives = 2;
+	int num_out_reads = 1;
+};
+
+static void flush_one(td_writer* w, size_t f)
+{
+	if (!w->buf[f].empty()) { fwrite(w->buf[f].data(), 1, w->buf[f].size(), w->files[f]); w->buf[f].clear(); }
+}
+
+extern "C" int td_writer_open(const char* prefix, const td_arch* a, td_writer** out)
+{
+	if (!prefix || !a || !out) return TD_FAIL;
+	td_writer* w = new td_writer();
+	int barsegment = -1, n_r = 0;
+	for (int i = 0; i < a->n_segments; i++) {
+		if (a->type[i] == 'B' && barsegment < 0) barsegment = i;
+		if (a->type[i] == 'R') n_r++;
+	}
+	w->num_out_reads = n_r;
+	w->num_alternatives = barsegment >= 0 ? a->n_seq[barsegment] : 2;
+	std::vector<std::string> names;
+	for (int i = 0; i < n_r; i++) { // io.c:859-915
+		const std::string rd = n_r > 1 ? "_READ" + std::to_string(i + 1) : "";
+		if (barsegment >= 0) {
+			for (int j = 0; j < w->num_alternatives - 1; j++) names.push_back(std::string(prefix) + "_BC_" + a->seqs[barsegment][j] + rd + ".fq");
+		} else {
+			names.push_back(std::string(prefix) + rd + ".fq");
+		}
+		names.push_back(std::string(prefix) + "_un" + rd + ".fq");
+	}
+	for (auto& nm : names) {
+		FILE* f = fopen(nm.c_str(), "w");
+		if (!f) { for (FILE* g : w->files) fclose(g); delete w; return TD_FAIL; }
+		w->files.push_back(f);
+	}
+	w->buf.resize(w->files.size());
+	*out = w;
+	return TD_OK;
+}
+
+extern "C" int td_writer_write(td_writer* w, const td_reads* rd, const td_read_result* res, const uint8_t* seq_out)
+{
+	if (!w || !rd || !res || !seq_out) return TD_FAIL;
+	if (w->files.empty()) return TD_OK;
+	static const char alphabet[] = "ACGTNN";
+	char head[64];
+	std::string seq, qual;
+	for (int64_t i = 0; i < rd->n_reads; i++) {
+		size_t f; // io.c:923-934
+		if (res[i].read_type == TD_EXTRACT_SUCCESS) f = (res[i].barcode != -1) ? (size_t)(res[i].barcode & 0xFF) : 0;
+		else f = (size_t)w->num_alternatives - 1;
+		const uint8_t* s = seq_out + rd->offs[i];
+		const int64_t len = rd->offs[i + 1] - rd->offs[i];
+		const char* q = rd->qual_off[i] >= 0 ? rd->text + rd->qual_off[i] : nullptr;
+		auto emit = [&]() { // io.c:955-975
+			if (f >= w->files.size()) return;
+			std::string& b = w->buf[f];
+			b += '@'; b.append(rd->text + rd->name_off[i], (size_t)rd->name_len[i]);
+			if (res[i].fingerprint != -1) { snprintf(head, sizeof head, ";FP:%d", res[i].fingerprint); b += head; }
+			snprintf(head, sizeof head, ";RQ:%0.2f\n", (double)res[i].mapq); b += head;
+			b += seq; b += "\n+\n"; b += qual; b += '\n';
+			if (b.size() > (1u << 20)) flush_one(w, f);
+		};
+		seq.clear(); qual.clear();
+		for (int64_t g = 0; g < len; g++) {
+			if (s[g] < 5) {
+				seq += alphabet[s[g]];
+				qual += q ? q[g] : '.';
+			} else if (!seq.empty()) {
+				emit();
+				f += (size_t)w->num_alternatives;
+				seq.clear(); qual.clear();
+			}
+		}
+		if (!seq.empty()) emit();
+	}
+	return TD_OK;
+}
+
+extern "C" int td_writer_close(td_writer* w)
+{
+	if (!w) return TD_FAIL;
+	int rc = TD_OK;
+	for (size_t f = 0; f < w->files.size(); f++) { flush_one(w, f); if (fclose(w->files[f]) != 0) rc = TD_FAIL; }
+	delete w;
+	return rc;
+}

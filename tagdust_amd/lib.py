@@ -21,6 +21,7 @@ ABI_SYMBOLS = [
     "td_batch_upload", "td_batch_upload_ascii", "td_run", "td_sync", "td_batch_download", "td_counts_reset",
     "td_counts_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_batch_info", "td_set_option", "td_spec_source",
 ]
+IO_ABI_SYMBOLS = ["td_reads_parse", "td_reads_free", "td_writer_open", "td_writer_write", "td_writer_close"]
 MODEL_ABI_SYMBOLS = ["td_arch_parse", "td_arch_free", "td_sequence_stats", "td_model_build", "td_model_tables_free"]
 
 RESULT_DTYPE = np.dtype([
@@ -31,6 +32,12 @@ RESULT_DTYPE = np.dtype([
 
 class TdError(RuntimeError):
     pass
+
+
+class _Reads(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("text", C.c_void_p), ("name_off", C.POINTER(C.c_int64)),
+                ("name_len", C.POINTER(C.c_int32)), ("qual_off", C.POINTER(C.c_int64)), ("offs", C.POINTER(C.c_int64)),
+                ("codes", C.POINTER(C.c_uint8))]
 
 
 class _SeqStats(C.Structure):
@@ -89,6 +96,12 @@ def load_library():
     lib.td_model_build.argtypes = [C.c_void_p, C.POINTER(_SeqStats), C.c_float, C.c_float, C.POINTER(C.c_void_p)]
     lib.td_model_tables_free.argtypes = [C.c_void_p]
     lib.td_model_tables_free.restype = None
+    lib.td_reads_parse.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.POINTER(_Reads))]
+    lib.td_reads_free.argtypes = [C.POINTER(_Reads)]
+    lib.td_reads_free.restype = None
+    lib.td_writer_open.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.td_writer_write.argtypes = [C.c_void_p, C.POINTER(_Reads), C.c_void_p, C.c_void_p]
+    lib.td_writer_close.argtypes = [C.c_void_p]
     _lib = lib
     return lib
 
@@ -163,6 +176,60 @@ def build_model(segments, codes, offs, e=0.05, d=0.1, stats_override=None):
             return md, stats
         finally:
             lib.td_model_tables_free(tab)
+    finally:
+        lib.td_arch_free(arch)
+
+
+class ParsedReads:
+    """FASTQ/FASTA text parsed by the library (include/tagdust_io.h); keeps the text buffer alive."""
+
+    def __init__(self, text, n_threads=0):
+        lib = load_library()
+        self._buf = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, np.uint8)
+        self._p = C.POINTER(_Reads)()
+        if lib.td_reads_parse(self._buf.ctypes.data, len(self._buf), int(n_threads), C.byref(self._p)) != 0:
+            raise TdError("td_reads_parse failed")
+        r = self._p.contents
+        self.n = int(r.n_reads)
+        self.offs = np.ctypeslib.as_array(r.offs, shape=(self.n + 1,)).copy()
+        self.codes = np.ctypeslib.as_array(r.codes, shape=(max(int(self.offs[-1]), 1),))[:int(self.offs[-1])].copy()
+        self.name_off = np.ctypeslib.as_array(r.name_off, shape=(max(self.n, 1),))[:self.n].copy()
+        self.name_len = np.ctypeslib.as_array(r.name_len, shape=(max(self.n, 1),))[:self.n].copy()
+        self.qual_off = np.ctypeslib.as_array(r.qual_off, shape=(max(self.n, 1),))[:self.n].copy()
+
+    def names(self):
+        b = self._buf.tobytes()
+        return [b[o:o + l] for o, l in zip(self.name_off, self.name_len)]
+
+    def close(self):
+        if self._p:
+            load_library().td_reads_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_demultiplexed(prefix, segments, reads, res, seq_out):
+    """print_all() for one input file through the library: res (RESULT_DTYPE) and seq_out as td_batch_download gives them."""
+    lib = load_library()
+    arr = (C.c_char_p * len(segments))(*[s.encode() for s in segments])
+    arch = C.c_void_p()
+    if lib.td_arch_parse(arr, len(segments), C.byref(arch)) != 0:
+        raise TdError("td_arch_parse failed")
+    try:
+        w = C.c_void_p()
+        if lib.td_writer_open(prefix.encode(), arch, C.byref(w)) != 0:
+            raise TdError("td_writer_open failed for %s" % prefix)
+        res = np.ascontiguousarray(res, RESULT_DTYPE)
+        seq_out = np.ascontiguousarray(seq_out, np.uint8)
+        rc = lib.td_writer_write(w, reads._p, res.ctypes.data, seq_out.ctypes.data)
+        rc |= lib.td_writer_close(w)
+        if rc != 0:
+            raise TdError("td_writer_write/close failed")
     finally:
         lib.td_arch_free(arch)
 

@@ -201,3 +201,40 @@ def test_runtime_hmm_loop_path(name, monkeypatch):
     for k in ("read_type", "barcode", "fingerprint"):
         assert np.array_equal(res[k], g[k]), k
     assert np.array_equal(seq_after, g["seq_after"])
+
+
+def test_long_linkers_from_host_model_builder(ctx):
+    """Architecture with a 20-nt 5' linker and a 34-nt 3' adapter (segments longer than the register-row limit of the
+    generic kernel), model built by the library's own host builder (include/tagdust_model.h) from the reads' statistics;
+    HIP == oracle on reads carrying partial linkers."""
+    from oracle import pyoracle
+    from tagdust_amd import lib as tdlib
+    rng = np.random.RandomState(7)
+    five, three = "ACGTTGCATCGGATCCTAGA", "AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC"
+    bars = ["ACAGTG", "CTTGTA", "GGCTAC", "TAGCTT"]
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    reads = []
+    for i in range(900):
+        k5, k3 = rng.randint(0, len(five) + 1), rng.randint(0, len(three) + 1)
+        s_ = five[len(five) - k5:] + bars[rng.randint(4)] + "".join("ACGT"[x] for x in rng.randint(0, 4, rng.randint(25, 60))) + three[:k3]
+        s_ = "".join(("ACGT"[rng.randint(4)] if rng.random_sample() < 0.02 else ch) for ch in s_)
+        if rng.random_sample() < 0.1:
+            s_ = "".join("ACGT"[x] for x in rng.randint(0, 4, len(s_)))
+        reads.append(np.array([code[ch] for ch in s_], np.uint8))
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    seq = np.concatenate(reads)
+    segs = ["P:" + five, "B:" + ",".join(bars), "R:N", "P:" + three]
+    md, st = tdlib.build_model(segs, seq, offs, 0.05, 0.1)
+    assert list(md["n_col"]) == [20, 6, 1, 34]
+    md.update(threshold=2.0, minlen=16, dust=100)
+    model = pyoracle.OracleModel(md)
+    ores, olab, oseq = pyoracle.label_batch(model, seq, offs, 2.0, 16, 100, 8)
+    assert (ores["read_type"] == 0).sum() > 300
+    res, labels, seq_after = _run(ctx, md, seq, offs, threshold=2.0)
+    for k in ("b_score", "f_score", "r_score", "bar_prob"):
+        assert np.array_equal(_bits(res[k]), _bits(ores[k])), k
+    assert np.array_equal(labels, olab)
+    assert np.allclose(res["mapq"], ores["Q"], rtol=0, atol=Q_TOL)
+    for k in ("read_type", "barcode", "fingerprint"):
+        assert np.array_equal(res[k], ores[k]), k
+    assert np.array_equal(seq_after, oseq)
