@@ -142,15 +142,9 @@ extern "C" void td_reads_free(td_reads* r)
 // ---------------------------------------------------------------------------------------------------------
 struct td_writer {
 	std::vector<FILE*> files;
-	std::vector<std::string> buf;
 	int num_alternatives = 2;
 	int num_out_reads = 1;
 };
-
-static void flush_one(td_writer* w, size_t f)
-{
-	if (!w->buf[f].empty()) { fwrite(w->buf[f].data(), 1, w->buf[f].size(), w->files[f]); w->buf[f].clear(); }
-}
 
 extern "C" int td_writer_open(const char* prefix, const td_arch* a, td_writer** out)
 {
@@ -178,19 +172,18 @@ extern "C" int td_writer_open(const char* prefix, const td_arch* a, td_writer** 
 		if (!f) { for (FILE* g : w->files) fclose(g); delete w; return TD_FAIL; }
 		w->files.push_back(f);
 	}
-	w->buf.resize(w->files.size());
 	*out = w;
 	return TD_OK;
 }
 
-extern "C" int td_writer_write(td_writer* w, const td_reads* rd, const td_read_result* res, const uint8_t* seq_out)
+// formats reads [lo, hi) into one buffer per output file (io.c:917-1001)
+static void format_range(const td_writer* w, const td_reads* rd, const td_read_result* res, const uint8_t* seq_out,
+                         int64_t lo, int64_t hi, std::vector<std::string>* bufs)
 {
-	if (!w || !rd || !res || !seq_out) return TD_FAIL;
-	if (w->files.empty()) return TD_OK;
 	static const char alphabet[] = "ACGTNN";
 	char head[64];
 	std::string seq, qual;
-	for (int64_t i = 0; i < rd->n_reads; i++) {
+	for (int64_t i = lo; i < hi; i++) {
 		size_t f; // io.c:923-934
 		if (res[i].read_type == TD_EXTRACT_SUCCESS) f = (res[i].barcode != -1) ? (size_t)(res[i].barcode & 0xFF) : 0;
 		else f = (size_t)w->num_alternatives - 1;
@@ -198,13 +191,12 @@ extern "C" int td_writer_write(td_writer* w, const td_reads* rd, const td_read_r
 		const int64_t len = rd->offs[i + 1] - rd->offs[i];
 		const char* q = rd->qual_off[i] >= 0 ? rd->text + rd->qual_off[i] : nullptr;
 		auto emit = [&]() { // io.c:955-975
-			if (f >= w->files.size()) return;
-			std::string& b = w->buf[f];
+			if (f >= bufs->size()) return;
+			std::string& b = (*bufs)[f];
 			b += '@'; b.append(rd->text + rd->name_off[i], (size_t)rd->name_len[i]);
 			if (res[i].fingerprint != -1) { snprintf(head, sizeof head, ";FP:%d", res[i].fingerprint); b += head; }
 			snprintf(head, sizeof head, ";RQ:%0.2f\n", (double)res[i].mapq); b += head;
 			b += seq; b += "\n+\n"; b += qual; b += '\n';
-			if (b.size() > (1u << 20)) flush_one(w, f);
 		};
 		seq.clear(); qual.clear();
 		for (int64_t g = 0; g < len; g++) {
@@ -219,6 +211,30 @@ extern "C" int td_writer_write(td_writer* w, const td_reads* rd, const td_read_r
 		}
 		if (!seq.empty()) emit();
 	}
+}
+
+extern "C" int td_writer_write(td_writer* w, const td_reads* rd, const td_read_result* res, const uint8_t* seq_out)
+{
+	if (!w || !rd || !res || !seq_out) return TD_FAIL;
+	if (w->files.empty()) return TD_OK;
+	// records are formatted by several threads over contiguous read ranges and appended range by range, so every file
+	// keeps the input order, like the reference's single loop
+	int nt = (int)std::thread::hardware_concurrency();
+	if (const char* e = getenv("TD_HOST_THREADS")) nt = atoi(e);
+	if (nt > 16) nt = 16;
+	if (nt < 1 || rd->n_reads < 65536) nt = 1;
+	std::vector<std::vector<std::string>> parts((size_t)nt, std::vector<std::string>(w->files.size()));
+	const int64_t per = (rd->n_reads + nt - 1) / nt;
+	std::vector<std::thread> th;
+	for (int t = 1; t < nt; t++) {
+		const int64_t lo = t * per, hi = lo + per < rd->n_reads ? lo + per : rd->n_reads;
+		if (lo < hi) th.emplace_back(format_range, w, rd, res, seq_out, lo, hi, &parts[(size_t)t]);
+	}
+	format_range(w, rd, res, seq_out, 0, per < rd->n_reads ? per : rd->n_reads, &parts[0]);
+	for (auto& t : th) t.join();
+	for (int t = 0; t < nt; t++)
+		for (size_t f = 0; f < w->files.size(); f++)
+			if (!parts[(size_t)t][f].empty()) fwrite(parts[(size_t)t][f].data(), 1, parts[(size_t)t][f].size(), w->files[f]);
 	return TD_OK;
 }
 
@@ -226,7 +242,7 @@ extern "C" int td_writer_close(td_writer* w)
 {
 	if (!w) return TD_FAIL;
 	int rc = TD_OK;
-	for (size_t f = 0; f < w->files.size(); f++) { flush_one(w, f); if (fclose(w->files[f]) != 0) rc = TD_FAIL; }
+	for (size_t f = 0; f < w->files.size(); f++) if (fclose(w->files[f]) != 0) rc = TD_FAIL;
 	delete w;
 	return rc;
 }

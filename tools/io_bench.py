@@ -40,7 +40,7 @@ def main(n=1 << 20):
         tdlib.write_demultiplexed(os.path.join(d, "out"), segs, pr, res, seq_out)
         dt = time.perf_counter() - t0
         sz = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
-        print("td_writer_write (1 thread): %.2f s  %.2f GB/s  %.1f M reads/s" % (dt, sz / dt / 1e9, n / dt / 1e6))
+        print("td_writer_write (up to 16 threads): %.2f s  %.2f GB/s  %.1f M reads/s" % (dt, sz / dt / 1e9, n / dt / 1e6))
 
 
 if __name__ == "__main__":
