@@ -282,7 +282,13 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 		c->spec_ready = true;
 		c->spec_block = td_spec_block_threads();
 		// resident waves per CU: two LDS tables fit a CU; a 1024-thread workgroup fills it alone
-		c->spec_waves_per_cu = (c->spec_block > 512) ? c->spec_block / TD_WAVE : 2 * (c->spec_block / TD_WAVE);
+		{
+			const int wpb = c->spec_block / TD_WAVE;
+			int blocks_per_cu = 32 / wpb;             // 32 waves per CU
+			if (blocks_per_cu > 2) blocks_per_cu = 2; // two 62.8 KB tables per 160 KB of LDS
+			if (blocks_per_cu < 1) blocks_per_cu = 1;
+			c->spec_waves_per_cu = blocks_per_cu * wpb;
+		}
 		const int by_regs = 4 * td_spec_min_waves();
 		if (c->spec_waves_per_cu > by_regs) c->spec_waves_per_cu = by_regs;
 	}
