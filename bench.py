@@ -150,7 +150,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=1 << 20, help="reads per step per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=20000, help="reads in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=60000, help="reads in the CPU baseline sample (0 = skip)")
     ap.add_argument("--check", type=int, default=2048, help="reads verified against the oracle before timing (0 = skip)")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS), help="development only; the bench line is c3")
     ap.add_argument("--specialize", type=int, default=1, help="0 = generic ahead-of-time kernel")
@@ -208,7 +208,9 @@ def main():
         if not ok:
             raise SystemExit("bench.py: HIP result differs from the oracle on the bench workload -- refusing to time it")
 
+    t_up = time.perf_counter()
     ctx.upload_batch(reads.reshape(-1), offs)   # resident in HBM from here on
+    t_up = time.perf_counter() - t_up
     del reads
     reduce_dev = torch.device("cuda", dev_index) if backend == "nccl" else None
     last_counts = [None]
@@ -251,6 +253,10 @@ def main():
             raise SystemExit("bench.py: reduced outcome counters (%d) do not add up to the reads decoded (%d)"
                              % (int(last_counts[0][:8].sum()), n * args.steps * world))
 
+    # host-side stages of the C-ABI, outside the timed region (reported, never part of `value`)
+    t_down = time.perf_counter()
+    ctx.download(labels=False, seq=True)
+    t_down = time.perf_counter() - t_down
     if rank == 0:
         total_reads = n * args.steps * world
         value = total_reads / elapsed
@@ -282,6 +288,9 @@ def main():
                          "note": "algorithmic bytes are tiny (220 B/read); the kernel is VALU/LDS-issue bound and its real HBM "
                                  "traffic is the backward-row spill (see DESIGN.md)"},
         }
+        out["host_stages"] = {"upload_pack_h2d_ms": t_up * 1e3, "download_d2h_unpack_ms": t_down * 1e3,
+                              "note": "td_batch_upload (2-bit packing on host threads + H2D) and td_batch_download (results + rewritten "
+                                      "sequences) for one batch; not included in value"}
         if args.cpu_sample and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, args.cpu_sample, seed=77)
         elif args.cpu_sample:
