@@ -208,8 +208,9 @@ def main():
         if not ok:
             raise SystemExit("bench.py: HIP result differs from the oracle on the bench workload -- refusing to time it")
 
+    ctx.upload_batch(reads.reshape(-1), offs)   # first upload allocates the HBM workspace
     t_up = time.perf_counter()
-    ctx.upload_batch(reads.reshape(-1), offs)   # resident in HBM from here on
+    ctx.upload_batch(reads.reshape(-1), offs)   # steady state; resident in HBM from here on
     t_up = time.perf_counter() - t_up
     del reads
     reduce_dev = torch.device("cuda", dev_index) if backend == "nccl" else None

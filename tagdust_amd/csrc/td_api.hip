@@ -87,6 +87,24 @@ struct td_ctx {
 	float last_ms = -1.0f;
 };
 
+// run fn(lo, hi) over [0, n) on up to 16 host threads (TD_HOST_THREADS overrides)
+template <typename F>
+static void parallel_ranges(int64_t n, F fn)
+{
+	int nt = (int)std::thread::hardware_concurrency();
+	if (const char* e = getenv("TD_HOST_THREADS")) nt = atoi(e);
+	if (nt > 16) nt = 16;
+	if (nt < 1 || n < 65536) nt = 1;
+	if (nt == 1) { fn((int64_t)0, n); return; }
+	std::vector<std::thread> th;
+	const int64_t per = (n + nt - 1) / nt;
+	for (int t = 0; t < nt; t++) {
+		const int64_t lo = t * per, hi = lo + per < n ? lo + per : n;
+		if (lo < hi) th.emplace_back(fn, lo, hi);
+	}
+	for (auto& t : th) t.join();
+}
+
 static int fail(td_ctx* c, const char* fmt, ...)
 {
 	char buf[512];
@@ -402,22 +420,7 @@ static int upload_common(td_ctx* c, const uint8_t* codes, const char* ascii, con
 			}
 		}
 	};
-	{
-		int nt = (int)std::thread::hardware_concurrency();
-		if (const char* e = getenv("TD_HOST_THREADS")) nt = atoi(e);
-		if (nt > 16) nt = 16;
-		if (nt < 1 || n < 65536) nt = 1;
-		if (nt == 1) pack_range(0, n);
-		else {
-			std::vector<std::thread> th;
-			const int64_t per = (n + nt - 1) / nt;
-			for (int t = 0; t < nt; t++) {
-				const int64_t lo = t * per, hi = lo + per < n ? lo + per : n;
-				if (lo < hi) th.emplace_back(pack_range, lo, hi);
-			}
-			for (auto& t : th) t.join();
-		}
-	}
+	parallel_ranges(n, pack_range);
 	if (ensure(c, &c->d_packed, &c->cap_packed, packed.size() * 4) != TD_OK) return TD_FAIL;
 	if (ensure(c, &c->d_lens, &c->cap_lens, lens.size() * 4) != TD_OK) return TD_FAIL;
 	if (!packed.empty()) HIPCHK(c, hipMemcpyAsync(c->d_packed, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -562,40 +565,46 @@ extern "C" int td_batch_download(td_ctx* c, td_read_result* res, int8_t* labels,
 		const float* r = (const float*)(h.data() + ol.r); const float* bar = (const float*)(h.data() + ol.bar);
 		const float* q = (const float*)(h.data() + ol.q); const int32_t* ty = (const int32_t*)(h.data() + ol.type);
 		const int32_t* bc = (const int32_t*)(h.data() + ol.barcode); const int32_t* fg = (const int32_t*)(h.data() + ol.finger);
-		for (int64_t i = 0; i < n; i++) {
-			const int64_t k = c->pos_of[(size_t)i];
-			res[i].f_score = f[k]; res[i].b_score = b[k]; res[i].r_score = r[k]; res[i].bar_prob = bar[k];
-			res[i].mapq = q[k]; res[i].read_type = ty[k]; res[i].barcode = bc[k]; res[i].fingerprint = fg[k];
-		}
+		parallel_ranges(n, [&](int64_t lo, int64_t hi) {
+			for (int64_t i = lo; i < hi; i++) {
+				const int64_t k = c->pos_of[(size_t)i];
+				res[i].f_score = f[k]; res[i].b_score = b[k]; res[i].r_score = r[k]; res[i].bar_prob = bar[k];
+				res[i].mapq = q[k]; res[i].read_type = ty[k]; res[i].barcode = bc[k]; res[i].fingerprint = fg[k];
+			}
+		});
 		(void)np;
 	}
 	if (labels) {
 		const size_t bytes = (size_t)c->n_tiles * (c->lmax + 1) * TD_WAVE;
 		std::vector<int8_t> h(bytes);
 		HIPCHK(c, hipMemcpy(h.data(), c->d_out + ol.labels, bytes, hipMemcpyDeviceToHost));
-		for (int64_t i = 0; i < n; i++) {
-			const int64_t k = c->pos_of[(size_t)i];
-			const int64_t tile = k / TD_WAVE; const int lane = (int)(k % TD_WAVE);
-			const int l = (int)(c->offs[i + 1] - c->offs[i]);
-			const int8_t* src = h.data() + tile * (int64_t)(c->lmax + 1) * TD_WAVE;
-			int8_t* dst = labels + c->offs[i] + i;
-			for (int k = 0; k <= l; k++) dst[k] = src[k * TD_WAVE + lane];
-		}
+		parallel_ranges(n, [&](int64_t lo, int64_t hi) {
+			for (int64_t i = lo; i < hi; i++) {
+				const int64_t k = c->pos_of[(size_t)i];
+				const int64_t tile = k / TD_WAVE; const int lane = (int)(k % TD_WAVE);
+				const int l = (int)(c->offs[i + 1] - c->offs[i]);
+				const int8_t* src = h.data() + tile * (int64_t)(c->lmax + 1) * TD_WAVE;
+				int8_t* dst = labels + c->offs[i] + i;
+				for (int kk = 0; kk <= l; kk++) dst[kk] = src[kk * TD_WAVE + lane];
+			}
+		});
 	}
 	if (seq_out) {
 		const size_t words = (size_t)c->n_tiles * c->nw1 * TD_WAVE;
 		std::vector<uint32_t> h(words);
 		HIPCHK(c, hipMemcpy(h.data(), c->d_out + ol.keep, words * 4, hipMemcpyDeviceToHost));
-		for (int64_t i = 0; i < n; i++) {
-			const int64_t k = c->pos_of[(size_t)i];
-			const int64_t tile = k / TD_WAVE; const int lane = (int)(k % TD_WAVE);
-			const int l = (int)(c->offs[i + 1] - c->offs[i]);
-			const uint32_t* kw = h.data() + tile * (int64_t)c->nw1 * TD_WAVE;
-			for (int k = 0; k < l; k++) {
-				const bool keep = (kw[(k >> 5) * TD_WAVE + lane] >> (k & 31)) & 1u;
-				seq_out[c->offs[i] + k] = keep ? c->codes_host[(size_t)(c->offs[i] + k)] : 65; // spacer byte, barcode_hmm.c:3348
+		parallel_ranges(n, [&](int64_t lo, int64_t hi) {
+			for (int64_t i = lo; i < hi; i++) {
+				const int64_t k = c->pos_of[(size_t)i];
+				const int64_t tile = k / TD_WAVE; const int lane = (int)(k % TD_WAVE);
+				const int l = (int)(c->offs[i + 1] - c->offs[i]);
+				const uint32_t* kw = h.data() + tile * (int64_t)c->nw1 * TD_WAVE;
+				for (int kk = 0; kk < l; kk++) {
+					const bool keep = (kw[(kk >> 5) * TD_WAVE + lane] >> (kk & 31)) & 1u;
+					seq_out[c->offs[i] + kk] = keep ? c->codes_host[(size_t)(c->offs[i] + kk)] : 65; // spacer byte, barcode_hmm.c:3348
+				}
 			}
-		}
+		});
 	}
 	return TD_OK;
 }
