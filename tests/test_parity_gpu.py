@@ -238,3 +238,42 @@ def test_long_linkers_from_host_model_builder(ctx):
     for k in ("read_type", "barcode", "fingerprint"):
         assert np.array_equal(res[k], ores[k]), k
     assert np.array_equal(seq_after, oseq)
+
+
+def test_abi_error_paths(ctx):
+    """Misuse is reported as TD_FAIL with a message (never a crash, never a silent fallback)."""
+    from tagdust_amd import TdError, TagdustHip
+    g = load_golden("c2_b4_r")
+    fresh = TagdustHip(0)
+    try:
+        with pytest.raises(TdError, match="no model"):
+            fresh.upload_batch(g["seq"], g["offs"])
+        with pytest.raises(TdError, match="no model"):
+            fresh.run()
+        bad = dict(g)
+        bad["A"] = g["A"] * 0.5
+        with pytest.raises(TdError, match="not 0/1|diagonal"):
+            fresh.upload_model(bad)
+        odd = dict(g)
+        odd["n_hmm"] = g["n_hmm"] + 1          # sizes that do not add up to H / C
+        with pytest.raises(TdError, match="inconsistent"):
+            fresh.upload_model(odd)
+        fresh.upload_model(g)
+        with pytest.raises(TdError, match="unsupported mode"):
+            fresh.upload_batch(g["seq"], g["offs"])
+            fresh.run(3)
+        with pytest.raises(TdError, match="unknown option"):
+            fresh.set_option("no_such_option", 1)
+    finally:
+        fresh.close()
+
+
+def test_model_reupload_uses_kernel_cache(ctx):
+    """Uploading the same architecture again must not recompile (the code object is cached by source hash)."""
+    import time
+    g = load_golden("c3_b6_s_r_p")
+    ctx.upload_model(g)
+    t0 = time.perf_counter()
+    ctx.upload_model(g)
+    dt = time.perf_counter() - t0
+    assert dt < 1.0, "re-upload took %.2f s" % dt
