@@ -286,6 +286,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "td_spec_kernel" if args.specialize else "td_decode_kernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_read": bpr, "reads_per_launch": n,
+                         "traffic_gbps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
+                         "traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "note": "algorithmic bytes are tiny (220 B/read); the kernel is VALU/LDS-issue bound and its real HBM "
                                  "traffic is the backward-row spill (see DESIGN.md)"},
         }

@@ -385,14 +385,17 @@ static int upload_common(td_ctx* c, const uint8_t* codes, const char* ascii, con
 	std::vector<uint32_t> packed((size_t)(n_tiles * tile_words), 0u);
 	std::vector<int32_t> lens((size_t)(n_tiles * TD_WAVE), 0);
 	c->codes_host.resize((size_t)offs[n]);
-	static uint8_t asc2code[256];
-	static bool asc_ready = false;
-	if (!asc_ready) { // init_nuc_code(), src/nuc_code.c:46-74: ACGTU (either case) -> 0..3(3), everything else 4
-		for (int k = 0; k < 256; k++) asc2code[k] = 4;
-		asc2code['A'] = asc2code['a'] = 0; asc2code['C'] = asc2code['c'] = 1; asc2code['G'] = asc2code['g'] = 2;
-		asc2code['T'] = asc2code['t'] = 3; asc2code['U'] = asc2code['u'] = 3;
-		asc_ready = true;
-	}
+	// init_nuc_code(), src/nuc_code.c:46-74: ACGTU (either case) -> 0..3(3), everything else 4 (thread-safe static init)
+	struct AscTable {
+		uint8_t t[256];
+		AscTable()
+		{
+			for (int k = 0; k < 256; k++) t[k] = 4;
+			t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3; t['U'] = t['u'] = 3;
+		}
+	};
+	static const AscTable asc_table;
+	const uint8_t* asc2code = asc_table.t;
 	// Reads are laid out on the device sorted by length (stable counting sort), so that the 64 reads of a tile have
 	// (nearly) the same length and no lane idles through another read's extra positions; results are un-permuted on
 	// download.  Per-read results do not depend on the order (every read is decoded independently).

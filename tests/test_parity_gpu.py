@@ -277,3 +277,38 @@ def test_model_reupload_uses_kernel_cache(ctx):
     ctx.upload_model(g)
     dt = time.perf_counter() - t0
     assert dt < 1.0, "re-upload took %.2f s" % dt
+
+
+def test_long_reads(ctx):
+    """400-bp reads (workspace and row strides scale with the batch's longest read); HIP == oracle."""
+    from oracle import pyoracle
+    g = load_golden("c2_b4_r")
+    rng = np.random.RandomState(3)
+    n = 200
+    lens = rng.randint(250, 401, n)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    seq = rng.randint(0, 4, int(offs[-1])).astype(np.uint8)
+    src = g["offs"]
+    for i in range(0, n, 2):
+        seq[offs[i]:offs[i] + 4] = g["seq"][src[i]:src[i] + 4]     # a real barcode in front
+    ores, olab, oseq = pyoracle.label_batch(pyoracle.OracleModel(g), seq, offs, float(g["threshold"]), 16, 100, 8)
+    res, labels, seq_after = _run(ctx, g, seq, offs)
+    for k in ("b_score", "f_score", "r_score", "bar_prob"):
+        assert np.array_equal(_bits(res[k]), _bits(ores[k])), k
+    assert np.array_equal(labels, olab) and np.array_equal(res["read_type"], ores["read_type"]) and np.array_equal(seq_after, oseq)
+
+
+def test_read_without_valid_path_is_a_mismatch(ctx):
+    """A read shorter than the number of mandatory segments has no valid path: b_score = -inf.  The reference then indexes
+    its logsum table with NaN and crashes; the device reports ARCHITECTURE_MISMATCH with Q = 0 and the
+    other reads of the batch are unaffected."""
+    g = load_golden("c2_b4_r")
+    n_good = 70
+    good = [g["seq"][g["offs"][i]:g["offs"][i + 1]] for i in range(n_good)]
+    reads = good[:35] + [np.array([2], np.uint8)] + good[35:]
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    res, labels, seq_after = _run(ctx, g, np.concatenate(reads), offs)
+    assert res["read_type"][35] == 1 and res["mapq"][35] == 0.0 and np.isneginf(res["b_score"][35])
+    keep = np.r_[0:35, 36:n_good + 1]
+    assert np.array_equal(res["read_type"][keep], g["read_type"][:n_good])
+    assert np.array_equal(_bits(res["f_score"][keep]), _bits(g["f_score"][:n_good]))
