@@ -1,4 +1,7 @@
-// td_kernels.hip -- TagDust2 per-read HMM decoding on gfx950 (MI355X), hand-written HIP.
+// td_kernels.hip -- TagDust2 per-read HMM decoding on gfx950 (MI355X), hand-written HIP: the GENERIC ahead-of-time
+// kernel, which reads the model from HBM (any model the ABI accepts, no per-model compile).  The default path is the
+// model-specialised kernel in td_spec_kernel.inc; this one serves td_set_option("specialize", 0) and the candidate
+// models of an architecture comparison.
 //
 // Mapping: ONE READ PER LANE.  A wave owns a tile of 64 reads and walks the read-architecture HMM with
 // wave-uniform control flow (segment j, HMM f, position i, column g are scalar loop counters), so every
@@ -42,23 +45,19 @@
 
 // ---------------------------------------------------------------------------------------------------------
 // logsum, src/misc.c:72-78:  (min == -inf || max-min >= 15.7f) ? max : max + T[(int)((max-min)*1000.0f)]
-// d = max-min is +inf when min == -inf and NaN when both are -inf; "d < 15.7f" is false for both, which
-// returns max exactly like the reference.  The index of dead lanes is clamped into the table.
+// 8 VALU + 1 ds_read_b32, no select: every "return max" case lands on a table slot that holds 0.
 // ---------------------------------------------------------------------------------------------------------
-__shared__ float g_T[TD_LOGSUM_LIVE];
+__shared__ float g_T[TD_LOGSUM_LIVE + 4]; // slot [TD_LOGSUM_LIVE] holds 0: "return max" without a select
 
 struct LdsTable {};   // tag: the table is the file-scope LDS array, never a generic pointer (a generic pointer
                       // turns every lookup into a flat_load that waits on vmcnt AND lgkmcnt)
 
 __device__ __forceinline__ float lsum(LdsTable, float a, float b)
 {
-	const float mx = (a > b) ? a : b;
-	const float mn = (a < b) ? a : b;
-	const float d = mx - mn;
-	const float dc = fminf(d, __uint_as_float(0x417B3332u)); // largest float < 15.7f
-	const int idx = (int)(dc * 1000.0f);
-	const float t = g_T[idx];
-	return (d < 15.7f) ? (mx + t) : mx;
+	// d >= 15.7f, d = +inf (one operand -inf) and d = NaN (both -inf) clamp to 15.7f -> index 15700 -> + 0.0f
+	const float mx = fmaxf(a, b);
+	const float dc = fminf(mx - fminf(a, b), 15.7f);
+	return mx + g_T[(int)(dc * 1000.0f)];
 }
 
 // Model tables are read through the constant address space: with a wave-uniform index the compiler then
@@ -85,11 +84,15 @@ __device__ __forceinline__ TdSeg load_seg(chdr_ptr hd, int j)
 // emission lookup with a per-lane base code and wave-uniform table (5 scalars)
 __device__ __forceinline__ float emit5(cfloat_ptr e, int c)
 {
-	float r = e[4];
-	r = (c == 3) ? e[3] : r;
-	r = (c == 2) ? e[2] : r;
-	r = (c == 1) ? e[1] : r;
-	r = (c == 0) ? e[0] : r;
+	// the five values are pinned in SGPRs first: otherwise the compiler folds "select of loads" into a per-lane
+	// indexed load from the table, i.e. a vector memory access per emission look-up
+	float e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
+	asm volatile("" : "+s"(e0), "+s"(e1), "+s"(e2), "+s"(e3), "+s"(e4));
+	float r = e4;
+	r = (c == 3) ? e3 : r;
+	r = (c == 2) ? e2 : r;
+	r = (c == 1) ? e1 : r;
+	r = (c == 0) ? e0 : r;
 	return r;
 }
 
@@ -437,7 +440,7 @@ __device__ __forceinline__ void fwd_segment_reg(const WaveCtx& w, const TdSeg sg
 __global__ __launch_bounds__(TD_BLOCK, 2) void td_decode_kernel(const TdKernelArgs ka)
 {
 	const LdsTable T{};
-	for (int k = threadIdx.x; k < TD_LOGSUM_LIVE; k += TD_BLOCK) g_T[k] = ka.logsum[k];
+	for (int k = threadIdx.x; k < TD_LOGSUM_LIVE + 4; k += TD_BLOCK) g_T[k] = (k < TD_LOGSUM_LIVE) ? ka.logsum[k] : 0.0f;
 	__syncthreads();
 
 	const int lane = threadIdx.x & (TD_WAVE - 1);
