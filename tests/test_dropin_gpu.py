@@ -97,3 +97,44 @@ def test_architecture_selection_through_gpu(tmp_path):
     assert cpu and set(cpu) == set(gpu)
     for k in cpu:
         assert cpu[k] == gpu[k], "output file *%s differs" % k
+
+
+# the other three scenarios of dev/bar_read_test.sh with their gold lines (dev/barread2_..., read_paired_..., barread_paired_...)
+GOLD2 = "tagdust\t1.0000\t0.9775\t0.9974\t0.9874\t0.0013\t8976.00\t23.00\t0.00\t1001.00"
+GOLD3 = "tagdust\t1.0000\t1.0000\t1.0000\t1.0000\t0.0017\t8999.00\t0.00\t0.00\t1001.00"
+SIM_COMMON = ["-sim_readlen", "20", "-sim_readlen_mod", "0", "-sim_numseq", "10000", "-sim_endloss", "0", "-sim_error_rate", "0.02"]
+
+
+def _sim(d, out, extra):
+    tags = os.path.join(REPO, "tests", "golden", "EDITTAG_6nt_ed_4_first4.txt")
+    _run("simreads_rtest", [tags, "-seed", "42"] + extra + SIM_COMMON + ["-o", out], d)
+
+
+def _eval(d, pattern, out):
+    fqs = sorted(glob.glob(os.path.join(d, pattern)))
+    assert fqs, pattern
+    _run("evalres_rtest", ["-name", "tagdust"] + [os.path.basename(f) for f in fqs] + ["-o", out], d)
+    return [l.strip() for l in open(os.path.join(d, out + "_results.txt")).read().splitlines()]
+
+
+@pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built")
+def test_bar_read_test_scenario2_gold(tmp_path):
+    """single-end, 5' and 3' partial linkers + barcode + read"""
+    d = str(tmp_path)
+    _sim(d, "barread2.fq", ["-sim_barnum", "4", "-sim_5seq", "GGGGGGG", "-sim_3seq", "TTTTTTT", "-sim_random_frac", "0.1"])
+    _run("tagdust_hip_rtest", ["-seed", "42", "barread2.fq", "-arch", "barread2.fq_tagdust_arch.txt", "-o", "barread2_tagdust"], d)
+    assert GOLD2 in _eval(d, "barread2_tagdust*.fq", "barread2_tagdust")
+
+
+@pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("barnum,gold", [("0", GOLD3), ("4", GOLD2)], ids=["scenario3_linkers", "scenario4_barcode"])
+def test_bar_read_test_paired_scenarios_gold(tmp_path, barnum, gold):
+    """paired-end: read 1 carries the architecture (through the GPU), read 2 is 'R:N'; outcomes and barcodes are
+    combined per record index by the reference's controller (barcode_hmm.c:329-351)"""
+    d = str(tmp_path)
+    _sim(d, "r1.fq", ["-sim_barnum", barnum, "-sim_5seq", "GGGGGGG", "-sim_3seq", "TTTTTTT", "-sim_random_frac", "0.1"])
+    _sim(d, "r2.fq", ["-sim_barnum", "0", "-sim_random_frac", "0.00"])
+    arch = open(os.path.join(d, "r1.fq_tagdust_arch.txt")).read() + open(os.path.join(d, "r2.fq_tagdust_arch.txt")).read()
+    open(os.path.join(d, "combo_arch.txt"), "w").write(arch)
+    _run("tagdust_hip_rtest", ["-seed", "42", "-sim_numseq", "1", "r1.fq", "r2.fq", "-arch", "combo_arch.txt", "-o", "paired_tagdust"], d)
+    assert gold in _eval(d, "paired_tagdust_*READ1.fq", "paired_tagdust")
