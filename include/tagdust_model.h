@@ -58,6 +58,30 @@ int  td_model_build(const td_arch* arch, const td_seq_stats* stats, float sequen
                     td_model_tables** out);
 void td_model_tables_free(td_model_tables* tables);
 
+/* ---- threshold calibration, estimateQthreshold() src/calibrateQ.c:17-235 ----
+ * The reference simulates 2*(n/4) reads from the model (emit_read_sequence, src/barcode_hmm.c:2696-3046) and
+ * 2*(n/4) reads from the background (emit_random_sequence, :2599-2680), scores them with run_pHMM(MODE_GET_PROB),
+ * sorts by Q and picks the Q that maximises sensitivity + specificity (capped at 20).  Emission is bound to the
+ * C library's rand() sequence, so it stays on the host; scoring is TD_MODE_GET_PROB on the device. */
+typedef struct td_calibration {
+	int64_t  n_reads;
+	uint8_t* codes;               /* emitted base codes, concatenated */
+	int64_t* offs;                /* [n_reads+1] */
+	uint8_t* is_random;           /* [n_reads] 0 = emitted from the model, 1 = from the background */
+	td_model_tables* scoring;     /* the model the reads are scored with (sequencer_error_rate forced to 0.05, calibrateQ.c:117) */
+} td_calibration;
+
+/* n_reads: 400000 in the reference (4000 in its -DRTEST builds).  rng: 0 = srand(seed)/rand() of the C library,
+ * 1 = the reference's private LCG of its -DRTEST builds (src/misc.c:878-887, RAND_MAX taken as 32768). */
+int   td_calibration_emit(const td_arch* arch, const td_seq_stats* stats, float indel_frequency, uint32_t seed,
+                          int32_t n_reads, int32_t rng, td_calibration** out);
+/* the sort + sweep of calibrateQ.c:146-212 on the per-read Q values */
+float td_calibration_select(const float* mapq, const uint8_t* is_random, int64_t n_reads);
+void  td_calibration_free(td_calibration* cal);
+/* emit -> td_model_upload(scoring) -> td_run(TD_MODE_GET_PROB) -> select.  Leaves the scoring model uploaded. */
+int   td_estimate_threshold(td_ctx* ctx, const td_arch* arch, const td_seq_stats* stats, float indel_frequency,
+                            uint32_t seed, int32_t n_reads, int32_t rng, float* threshold);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../include/tagdust_model.h"
@@ -434,4 +435,241 @@ extern "C" void td_model_tables_free(td_model_tables* t)
 	if (!t) return;
 	free(t->storage);
 	free(t);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// threshold calibration, calibrateQ.c:17-235
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Rng {
+	int kind;            // 0 = libc rand(), 1 = the reference's RTEST LCG (misc.c:878-887)
+	uint32_t next = 1;
+	void seed(uint32_t s) { if (kind) next = s; else srand(s); }
+	// "(float)rand()/(float)my_rand_max", barcode_hmm.c:2610,2721 (my_rand_max = RAND_MAX, or 32768 under RTEST)
+	double draw()
+	{
+		if (kind) {
+			next = next * 1103515245u + 12345u;
+			return (float)(int)((unsigned)(next / 65536) % 32768) / (float)32768u;
+		}
+		return (float)rand() / (float)(unsigned)RAND_MAX;
+	}
+};
+
+struct ModelView { // flattened tables with the per-segment offsets the emitters need
+	const td_model_desc* m;
+	std::vector<int> col_off;
+	explicit ModelView(const td_model_desc* d) : m(d), col_off((size_t)d->S)
+	{
+		int c = 0;
+		for (int j = 0; j < d->S; j++) { col_off[(size_t)j] = c; c += d->n_hmm[j] * d->n_col[j]; }
+	}
+	int col(int seg, int hmm, int g) const { return col_off[(size_t)seg] + hmm * m->n_col[seg] + g; }
+};
+
+// emit_read_sequence(), barcode_hmm.c:2696-3046
+void emit_read(const ModelView& v, Rng& rng, int average_length, std::vector<uint8_t>& seq)
+{
+	const td_model_desc* m = v.m;
+	double r = rng.draw();
+	double sum;
+	size_t current_length = 0;
+	seq.clear();
+	while ((int)current_length < average_length) {
+		int state = 0, column = 0, hmm = 0, segment = 0; // 0 silent, 1 M, 2 I, 3 D
+		while (1) {
+			r = rng.draw();
+			sum = p2sp(0.0f);
+			switch (state) {
+			case 0: {
+				const int len = m->n_col[segment];
+				bool done = false;
+				for (int i = 0; i < m->n_hmm[segment] && !done; i++) {
+					for (int j = 0; j < len; j++) {
+						sum = logsum_f(sum, m->sM[v.col(segment, i, j)]);
+						if (r < sp2p(sum)) { state = 1; column = j; hmm = i; done = true; break; }
+						sum = logsum_f(sum, m->sI[v.col(segment, i, j)]);
+						if (r < sp2p(sum)) { state = 2; column = j; hmm = i; done = true; break; }
+					}
+				}
+				break;
+			}
+			case 1: {
+				const float* t = m->trans + (size_t)v.col(segment, hmm, column) * 9;
+				sum = logsum_f(sum, t[MM]);
+				if (r < sp2p(sum)) { state = 1; column++; break; }
+				sum = logsum_f(sum, t[MI]);
+				if (r < sp2p(sum)) { state = 2; break; }
+				sum = logsum_f(sum, t[MD]);
+				if (r < sp2p(sum)) { state = 3; column++; break; }
+				state = 0; segment++; column = 0; hmm = 0; // MSKIP takes whatever is left
+				break;
+			}
+			case 2: {
+				const float* t = m->trans + (size_t)v.col(segment, hmm, column) * 9;
+				sum = logsum_f(sum, t[II]);
+				if (r < sp2p(sum)) { state = 2; break; }
+				sum = logsum_f(sum, t[IM]);
+				if (r < sp2p(sum)) { state = 1; column++; break; }
+				state = 0; segment++; column = 0; hmm = 0; // ISKIP
+				break;
+			}
+			case 3: {
+				const float* t = m->trans + (size_t)v.col(segment, hmm, column) * 9;
+				sum = logsum_f(sum, t[DD]);
+				if (r < sp2p(sum)) { state = 3; column++; break; }
+				state = 1; column++; // DM
+				break;
+			}
+			}
+			r = rng.draw();
+			sum = p2sp(0.0f);
+			if (state == 1 || state == 2) {
+				const float* e = (state == 1 ? m->eM : m->eI) + (size_t)v.col(segment, hmm, column) * 5;
+				for (int nuc = 0; nuc < 5; nuc++) {
+					sum = logsum_f(sum, e[nuc]);
+					if (r < sp2p(sum)) {
+						if (seq.size() <= current_length) seq.resize(current_length + 1);
+						seq[current_length++] = (uint8_t)nuc;
+						break;
+					}
+				}
+			}
+			if (segment == m->S) break;
+		}
+		if ((int)current_length < average_length) current_length = 0;
+	}
+	seq.resize(current_length);
+}
+
+// emit_random_sequence(), barcode_hmm.c:2599-2680
+void emit_random(const td_model_desc* m, Rng& rng, int average_length, std::vector<uint8_t>& seq)
+{
+	size_t current_length = 0;
+	double r = rng.draw();
+	double sum;
+	seq.clear();
+	while ((int)current_length < average_length) {
+		while (1) {
+			sum = p2sp(0.0f);
+			for (int nuc = 0; nuc < 5; nuc++) {
+				sum = logsum_f(sum, m->bg[nuc]);
+				if (r < sp2p(sum)) {
+					if (seq.size() <= current_length) seq.resize(current_length + 1);
+					seq[current_length++] = (uint8_t)nuc;
+					break;
+				}
+			}
+			r = rng.draw();
+			if (r > 1.0 - (1.0 / (float)average_length)) break;
+		}
+		if ((int)current_length < average_length) current_length = 0;
+	}
+	seq.resize(current_length);
+}
+
+} // namespace
+
+extern "C" int td_calibration_emit(const td_arch* a, const td_seq_stats* ssi, float d, uint32_t seed, int32_t n_reads,
+                                   int32_t rng_kind, td_calibration** out)
+{
+	if (!a || !ssi || !out || n_reads < 4) return TD_FAIL;
+	Rng rng; rng.kind = rng_kind != 0;
+	rng.seed(seed);                                    // srand(seed), calibrateQ.c:33
+	const int binsize = n_reads / 4;
+	td_model_tables* em = nullptr;
+	if (td_model_build(a, ssi, 0.05f, d, &em) != TD_OK) return TD_FAIL; // sequencer_error_rate forced to 0.05, :65
+	// reads are emitted from a model whose B / S decoy HMM has prior 0 (:70-86)
+	{
+		int c = 0;
+		float* sM = const_cast<float*>(em->desc.sM);
+		for (int j = 0; j < em->desc.S; j++) {
+			const int n = em->desc.n_hmm[j], nc = em->desc.n_col[j];
+			if (a->type[j] == 'B' || a->type[j] == 'S') {
+				for (int f = 0; f < n - 1; f++) sM[c + f * nc] = p2sp(1.0 / (float)(n - 1));
+				sM[c + (n - 1) * nc] = p2sp(0.0);
+			}
+			c += n * nc;
+		}
+	}
+	td_calibration* cal = (td_calibration*)calloc(1, sizeof(td_calibration));
+	std::vector<uint8_t> all, one;
+	std::vector<int64_t> offs(1, 0);
+	std::vector<uint8_t> rnd;
+	const ModelView view(&em->desc);
+	const int avg = (int)ssi->average_length;
+	int readnum = 0;
+	for (int i = 0; i < binsize * 2; i++) {             // :88-100
+		emit_read(view, rng, avg, one);
+		all.insert(all.end(), one.begin(), one.end());
+		offs.push_back((int64_t)all.size()); rnd.push_back(0);
+		readnum++;
+	}
+	for (int i = 0; i < binsize + binsize; i++) {       // :102-113
+		emit_random(&em->desc, rng, avg, one);
+		all.insert(all.end(), one.begin(), one.end());
+		offs.push_back((int64_t)all.size()); rnd.push_back(1);
+		readnum++;
+		if (readnum == n_reads) break;
+	}
+	td_model_tables_free(em);
+	if (td_model_build(a, ssi, 0.05f, d, &cal->scoring) != TD_OK) { free(cal); return TD_FAIL; } // :117-119
+	cal->n_reads = readnum;
+	cal->codes = (uint8_t*)malloc(all.size() + 1);
+	cal->offs = (int64_t*)malloc(sizeof(int64_t) * offs.size());
+	cal->is_random = (uint8_t*)malloc(rnd.size() + 1);
+	if (!cal->codes || !cal->offs || !cal->is_random) { td_calibration_free(cal); return TD_FAIL; }
+	memcpy(cal->codes, all.data(), all.size());
+	memcpy(cal->offs, offs.data(), sizeof(int64_t) * offs.size());
+	memcpy(cal->is_random, rnd.data(), rnd.size());
+	*out = cal;
+	return TD_OK;
+}
+
+extern "C" void td_calibration_free(td_calibration* c)
+{
+	if (!c) return;
+	free(c->codes); free(c->offs); free(c->is_random);
+	td_model_tables_free(c->scoring);
+	free(c);
+}
+
+extern "C" float td_calibration_select(const float* mapq, const uint8_t* is_random, int64_t n)
+{
+	// calibrateQ.c:146-212.  qsort() of glibc 2.35 is a merge sort for arrays of this size, i.e. stable: equal Q values
+	// keep their emission order (model reads before background reads).
+	std::vector<int64_t> order((size_t)n);
+	for (int64_t i = 0; i < n; i++) order[(size_t)i] = i;
+	std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return mapq[x] > mapq[y]; });
+	double TP = 0.0, FP = 0.0, TN = 0.0, FN = 0.0;
+	for (int64_t i = 0; i < n; i++) { if (is_random[i]) TN++; else FN++; }
+	float best = 0.0f, thres4 = 1000.0f;
+	for (int64_t k = 0; k < n; k++) {
+		const int64_t i = order[(size_t)k];
+		if (is_random[i]) { FP += 1.0; TN -= 1.0; } else { TP += 1.0; FN -= 1.0; }
+		const float sensitivity = TP / (TP + FN);
+		const float specificity = TN / (TN + FP);
+		if (sensitivity + specificity > best) { best = specificity + sensitivity; thres4 = mapq[i]; }
+	}
+	return thres4 < 20 ? thres4 : 20.0f;
+}
+
+extern "C" int td_estimate_threshold(td_ctx* ctx, const td_arch* a, const td_seq_stats* ssi, float d, uint32_t seed,
+                                     int32_t n_reads, int32_t rng, float* threshold)
+{
+	if (!ctx || !threshold) return TD_FAIL;
+	td_calibration* cal = nullptr;
+	if (td_calibration_emit(a, ssi, d, seed, n_reads, rng, &cal) != TD_OK) return TD_FAIL;
+	int rc = TD_FAIL;
+	std::vector<td_read_result> res((size_t)cal->n_reads);
+	if (td_model_upload(ctx, &cal->scoring->desc) == TD_OK && td_batch_upload(ctx, cal->codes, cal->offs, cal->n_reads) == TD_OK &&
+	    td_run(ctx, TD_MODE_GET_PROB) == TD_OK && td_batch_download(ctx, res.data(), nullptr, nullptr) == TD_OK) {
+		std::vector<float> q((size_t)cal->n_reads);
+		for (int64_t i = 0; i < cal->n_reads; i++) q[(size_t)i] = res[(size_t)i].mapq;
+		*threshold = td_calibration_select(q.data(), cal->is_random, cal->n_reads);
+		rc = TD_OK;
+	}
+	td_calibration_free(cal);
+	return rc;
 }

@@ -22,7 +22,8 @@ ABI_SYMBOLS = [
     "td_counts_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_batch_info", "td_set_option", "td_spec_source",
 ]
 IO_ABI_SYMBOLS = ["td_reads_parse", "td_reads_free", "td_writer_open", "td_writer_write", "td_writer_close"]
-MODEL_ABI_SYMBOLS = ["td_arch_parse", "td_arch_free", "td_sequence_stats", "td_model_build", "td_model_tables_free"]
+MODEL_ABI_SYMBOLS = ["td_arch_parse", "td_arch_free", "td_sequence_stats", "td_model_build", "td_model_tables_free",
+                     "td_calibration_emit", "td_calibration_select", "td_calibration_free", "td_estimate_threshold"]
 
 RESULT_DTYPE = np.dtype([
     ("f_score", "<f4"), ("b_score", "<f4"), ("r_score", "<f4"), ("bar_prob", "<f4"), ("mapq", "<f4"),
@@ -38,6 +39,11 @@ class _Reads(C.Structure):
     _fields_ = [("n_reads", C.c_int64), ("text", C.c_void_p), ("name_off", C.POINTER(C.c_int64)),
                 ("name_len", C.POINTER(C.c_int32)), ("qual_off", C.POINTER(C.c_int64)), ("offs", C.POINTER(C.c_int64)),
                 ("codes", C.POINTER(C.c_uint8))]
+
+
+class _Calibration(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("codes", C.POINTER(C.c_uint8)), ("offs", C.POINTER(C.c_int64)),
+                ("is_random", C.POINTER(C.c_uint8)), ("scoring", C.c_void_p)]
 
 
 class _SeqStats(C.Structure):
@@ -96,6 +102,14 @@ def load_library():
     lib.td_model_build.argtypes = [C.c_void_p, C.POINTER(_SeqStats), C.c_float, C.c_float, C.POINTER(C.c_void_p)]
     lib.td_model_tables_free.argtypes = [C.c_void_p]
     lib.td_model_tables_free.restype = None
+    lib.td_calibration_emit.argtypes = [C.c_void_p, C.POINTER(_SeqStats), C.c_float, C.c_uint32, C.c_int32, C.c_int32,
+                                        C.POINTER(C.POINTER(_Calibration))]
+    lib.td_calibration_select.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.td_calibration_select.restype = C.c_float
+    lib.td_calibration_free.argtypes = [C.POINTER(_Calibration)]
+    lib.td_calibration_free.restype = None
+    lib.td_estimate_threshold.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_SeqStats), C.c_float, C.c_uint32, C.c_int32, C.c_int32,
+                                          C.POINTER(C.c_float)]
     lib.td_reads_parse.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.POINTER(_Reads))]
     lib.td_reads_free.argtypes = [C.POINTER(_Reads)]
     lib.td_reads_free.restype = None
@@ -176,6 +190,59 @@ def build_model(segments, codes, offs, e=0.05, d=0.1, stats_override=None):
             return md, stats
         finally:
             lib.td_model_tables_free(tab)
+    finally:
+        lib.td_arch_free(arch)
+
+
+def _arch_and_stats(lib, segments, codes, offs):
+    arr = (C.c_char_p * len(segments))(*[s.encode() for s in segments])
+    arch = C.c_void_p()
+    if lib.td_arch_parse(arr, len(segments), C.byref(arch)) != 0:
+        raise TdError("td_arch_parse failed for %r" % (segments,))
+    codes = np.ascontiguousarray(codes, np.uint8)
+    offs = np.ascontiguousarray(offs, np.int64)
+    st = _SeqStats()
+    if lib.td_sequence_stats(arch, codes.ctypes.data, offs.ctypes.data, len(offs) - 1, C.byref(st)) != 0:
+        lib.td_arch_free(arch)
+        raise TdError("td_sequence_stats failed")
+    return arch, st
+
+
+def calibration_emit(segments, codes, offs, d=0.1, seed=42, n_reads=400000, rng=0):
+    """The simulated reads of the reference's threshold calibration (calibrateQ.c:88-113) for this architecture and
+    these sequence statistics: returns (codes, offs, is_random)."""
+    lib = load_library()
+    arch, st = _arch_and_stats(lib, segments, codes, offs)
+    try:
+        p = C.POINTER(_Calibration)()
+        if lib.td_calibration_emit(arch, C.byref(st), float(d), int(seed), int(n_reads), int(rng), C.byref(p)) != 0:
+            raise TdError("td_calibration_emit failed")
+        c = p.contents
+        n = int(c.n_reads)
+        o = np.ctypeslib.as_array(c.offs, shape=(n + 1,)).copy()
+        out = (np.ctypeslib.as_array(c.codes, shape=(int(o[-1]),)).copy(), o, np.ctypeslib.as_array(c.is_random, shape=(n,)).copy())
+        lib.td_calibration_free(p)
+        return out
+    finally:
+        lib.td_arch_free(arch)
+
+
+def calibration_select(mapq, is_random):
+    lib = load_library()
+    q = np.ascontiguousarray(mapq, np.float32)
+    r = np.ascontiguousarray(is_random, np.uint8)
+    return float(np.float32(lib.td_calibration_select(q.ctypes.data, r.ctypes.data, len(q))))
+
+
+def estimate_threshold(ctx, segments, codes, offs, d=0.1, seed=42, n_reads=400000, rng=0):
+    """estimateQthreshold() with the scoring on the GPU (TD_MODE_GET_PROB)."""
+    lib = load_library()
+    arch, st = _arch_and_stats(lib, segments, codes, offs)
+    try:
+        thr = C.c_float()
+        if lib.td_estimate_threshold(ctx.h, arch, C.byref(st), float(d), int(seed), int(n_reads), int(rng), C.byref(thr)) != 0:
+            raise TdError(lib.td_last_error(ctx.h).decode() or "td_estimate_threshold failed")
+        return float(np.float32(thr.value))
     finally:
         lib.td_arch_free(arch)
 
