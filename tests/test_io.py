@@ -121,3 +121,33 @@ def test_io_gpu(tmp_path, name):
     assert set(got) == set(want)
     for k in want:
         assert got[k] == want[k], k
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref/tagdust_rtest not built")
+@pytest.mark.parametrize("name", ["c2_b4_r", "c3_b6_s_r_p", "scen2_p_b_r_p"])
+def test_whole_pipeline_without_the_reference(tmp_path, name):
+    """Everything from the library alone -- parse FASTQ, sequence statistics, model construction, threshold calibration
+    (emission on the host, scoring on the GPU), decoding, demultiplexed output -- must write the files the unmodified
+    reference CLI writes for the same command line."""
+    from tagdust_amd import TagdustHip
+    g = load_golden(name)
+    want = reference_outputs(g, str(tmp_path))
+    segs = segments_of(g)
+    pr = tdlib.ParsedReads(fastq_text(g), 2)
+    c = TagdustHip(0)
+    try:
+        thr = tdlib.estimate_threshold(c, segs, pr.codes, pr.offs, float(g["d"]), seed=42, n_reads=4000, rng=1)
+        model, _ = tdlib.build_model(segs, pr.codes, pr.offs, 0.05, float(g["d"]))   # calibration leaves e = 0.05 (calibrateQ.c:117)
+        c.upload_model(model)
+        c.set_params(thr, 16, 100)
+        c.upload_batch(pr.codes, pr.offs)
+        c.run()
+        res, _, seq_out = c.download(labels=False)
+    finally:
+        c.close()
+    tdlib.write_demultiplexed(str(tmp_path / "own"), segs, pr, res, seq_out)
+    got = {os.path.basename(f)[3:]: open(f, "rb").read() for f in glob.glob(str(tmp_path / "own*.fq"))}
+    assert set(got) == set(want)
+    for k in want:
+        assert got[k] == want[k], k
