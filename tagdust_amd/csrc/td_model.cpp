@@ -247,7 +247,15 @@ extern "C" void td_arch_free(td_arch* a)
 // ---------------------------------------------------------------------------------------------------------
 // get_sequence_stats(), io.c:52-300
 // ---------------------------------------------------------------------------------------------------------
+static int sequence_stats_limit(const td_arch* a, const uint8_t* codes, const int64_t* offs, int64_t n_reads, td_seq_stats* ssi, int64_t scan_limit);
+
 extern "C" int td_sequence_stats(const td_arch* a, const uint8_t* codes, const int64_t* offs, int64_t n_reads, td_seq_stats* ssi)
+{
+	// the reference reads batches of num_query = 1 000 001 reads and stops once more than 1 000 000 were seen (io.c:184)
+	return sequence_stats_limit(a, codes, offs, n_reads, ssi, 1000001);
+}
+
+static int sequence_stats_limit(const td_arch* a, const uint8_t* codes, const int64_t* offs, int64_t n_reads, td_seq_stats* ssi, int64_t scan_limit)
 {
 	if (!a || !codes || !offs || !ssi || n_reads < 0) return TD_FAIL;
 	memset(ssi, 0, sizeof *ssi);
@@ -266,8 +274,7 @@ extern "C" int td_sequence_stats(const td_arch* a, const uint8_t* codes, const i
 		for (int i = 0; i < three_len; i++) three.push_back(nuc_code(a->seqs[last][0][i]));
 	}
 	double five_s0 = 0, five_s1 = 0, five_s2 = 0, three_s0 = 0, three_s1 = 0, three_s2 = 0;
-	// the reference reads batches of num_query = 1 000 001 reads and stops once more than 1 000 000 were seen (:184)
-	const int64_t total_read = n_reads < 1000001 ? n_reads : 1000001;
+	const int64_t total_read = n_reads < scan_limit ? n_reads : scan_limit;
 	for (int64_t r = 0; r < total_read; r++) {
 		const uint8_t* seq = codes + offs[r];
 		const int len = (int)(offs[r + 1] - offs[r]);
@@ -672,4 +679,57 @@ extern "C" int td_estimate_threshold(td_ctx* ctx, const td_arch* a, const td_seq
 	}
 	td_calibration_free(cal);
 	return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// architecture selection, test_architectures.c:20-289
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int td_compare_architectures(td_ctx* ctx, const td_arch* const* archs, int32_t n_arch, const uint8_t* codes,
+                                        const int64_t* offs, int64_t n_reads, float e, float d, int32_t n_threads,
+                                        float* posterior, int32_t* best)
+{
+	if (!ctx || !archs || n_arch < 1 || !codes || !offs || !posterior || !best || n_reads < 1) return TD_FAIL;
+	if (n_threads < 1) n_threads = 1;
+	// test_architectures() sets num_query = 100 000 (:38-42): statistics then scan batches of 100 000 reads until more than
+	// 1 000 000 were seen (1 100 000 reads), and the candidates are scored on the first batch only (:182-184)
+	const int64_t n_score = n_reads < 100000 ? n_reads : 100000;
+	std::vector<td_read_result> res((size_t)n_score);
+	int rc = td_set_option(ctx, "specialize", 0);
+	for (int k = 0; k < n_arch && rc == TD_OK; k++) {
+		td_seq_stats st;
+		td_model_tables* m = nullptr;
+		if (sequence_stats_limit(archs[k], codes, offs, n_reads, &st, 1100000) != TD_OK || td_model_build(archs[k], &st, e, d, &m) != TD_OK) { rc = TD_FAIL; break; }
+		if (td_model_upload(ctx, &m->desc) != TD_OK || td_batch_upload(ctx, codes, offs, n_score) != TD_OK ||
+		    td_run(ctx, TD_MODE_ARCH_COMP) != TD_OK || td_batch_download(ctx, res.data(), nullptr, nullptr) != TD_OK) rc = TD_FAIL;
+		td_model_tables_free(m);
+		if (rc != TD_OK) break;
+		float total = p2sp(1.0);                                      // ab->arch_posterior[i] = prob2scaledprob(1.0), test_architectures.c:164
+		const int64_t interval = n_score / n_threads;                  // barcode_hmm.c:1911
+		for (int t = 0; t < n_threads; t++) {
+			const int64_t lo = t * interval, hi = (t == n_threads - 1) ? n_score : (t + 1) * interval;
+			float partial = p2sp(1.0);                                 // :1935
+			for (int64_t i = lo; i < hi; i++) partial += res[(size_t)i].b_score; // do_arch_comparison :2135
+			total += partial;                                          // :2003
+		}
+		posterior[k] = total;
+	}
+	(void)td_set_option(ctx, "specialize", 1);
+	if (rc != TD_OK) return TD_FAIL;
+	if (n_arch > 1) {
+		float sum = posterior[0];                                      // barcode_hmm.c:2009-2016
+		for (int k = 1; k < n_arch; k++) sum = logsum_f(sum, posterior[k]);
+		for (int k = 0; k < n_arch; k++) posterior[k] = posterior[k] - sum;
+		sum = p2sp(0.0f);                                              // test_architectures.c:191-206
+		for (int k = 0; k < n_arch; k++) sum = logsum_f(sum, posterior[k]);
+		*best = -1;
+		float best_score = -1.0f;
+		for (int k = 0; k < n_arch; k++) {
+			posterior[k] = sp2p(posterior[k] - sum);
+			if (posterior[k] > best_score) { best_score = posterior[k]; *best = k; }
+		}
+	} else {
+		posterior[0] = 1.0f;
+		*best = 0;
+	}
+	return TD_OK;
 }

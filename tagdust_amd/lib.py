@@ -23,7 +23,8 @@ ABI_SYMBOLS = [
 ]
 IO_ABI_SYMBOLS = ["td_reads_parse", "td_reads_free", "td_writer_open", "td_writer_write", "td_writer_close"]
 MODEL_ABI_SYMBOLS = ["td_arch_parse", "td_arch_free", "td_sequence_stats", "td_model_build", "td_model_tables_free",
-                     "td_calibration_emit", "td_calibration_select", "td_calibration_free", "td_estimate_threshold"]
+                     "td_calibration_emit", "td_calibration_select", "td_calibration_free", "td_estimate_threshold",
+                     "td_compare_architectures"]
 
 RESULT_DTYPE = np.dtype([
     ("f_score", "<f4"), ("b_score", "<f4"), ("r_score", "<f4"), ("bar_prob", "<f4"), ("mapq", "<f4"),
@@ -110,6 +111,8 @@ def load_library():
     lib.td_calibration_free.restype = None
     lib.td_estimate_threshold.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_SeqStats), C.c_float, C.c_uint32, C.c_int32, C.c_int32,
                                           C.POINTER(C.c_float)]
+    lib.td_compare_architectures.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                             C.c_float, C.c_float, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
     lib.td_reads_parse.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.POINTER(_Reads))]
     lib.td_reads_free.argtypes = [C.POINTER(_Reads)]
     lib.td_reads_free.restype = None
@@ -245,6 +248,31 @@ def estimate_threshold(ctx, segments, codes, offs, d=0.1, seed=42, n_reads=40000
         return float(np.float32(thr.value))
     finally:
         lib.td_arch_free(arch)
+
+
+def compare_architectures(ctx, candidates, codes, offs, e=0.05, d=0.1, n_threads=8):
+    """test_architectures(): candidates = list of segment-string lists; returns (posteriors float32[n], best index)."""
+    lib = load_library()
+    handles = []
+    try:
+        for segs in candidates:
+            arr = (C.c_char_p * len(segs))(*[s.encode() for s in segs])
+            h = C.c_void_p()
+            if lib.td_arch_parse(arr, len(segs), C.byref(h)) != 0:
+                raise TdError("td_arch_parse failed for %r" % (segs,))
+            handles.append(h)
+        arr = (C.c_void_p * len(handles))(*[h.value for h in handles])
+        codes = np.ascontiguousarray(codes, np.uint8)
+        offs = np.ascontiguousarray(offs, np.int64)
+        post = np.zeros(len(handles), np.float32)
+        best = C.c_int32(-1)
+        if lib.td_compare_architectures(ctx.h, arr, len(handles), codes.ctypes.data, offs.ctypes.data, len(offs) - 1,
+                                        float(e), float(d), int(n_threads), post.ctypes.data, C.byref(best)) != 0:
+            raise TdError(lib.td_last_error(ctx.h).decode() or "td_compare_architectures failed")
+        return post, int(best.value)
+    finally:
+        for h in handles:
+            lib.td_arch_free(h)
 
 
 class ParsedReads:

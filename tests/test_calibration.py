@@ -45,3 +45,48 @@ def test_estimate_threshold_on_gpu(name):
     finally:
         c.close()
     assert np.float32(thr).view(np.uint32) == np.float32(g["threshold"]).view(np.uint32), (thr, float(g["threshold"]))
+
+
+@pytest.mark.gpu
+def test_compare_architectures_on_gpu():
+    """td_compare_architectures (test_architectures(), backward-only scoring on the GPU) against the same quantity formed
+    from the oracle's b_scores with the reference's summation order; the winner is the architecture the reads were
+    simulated with (and what the reference CLI picks, tests/test_dropin_gpu.py)."""
+    from oracle import pyoracle
+    from tagdust_amd import TagdustHip
+    g = load_golden("c2_b4_r")
+    real = _segments(g)
+    cands = [["R:N"], real, ["B:GGGG,CCCC", "R:N"]]
+    T = 3
+    c = TagdustHip(0)
+    try:
+        post, best = tdlib.compare_architectures(c, cands, g["seq"], g["offs"], 0.05, 0.1, n_threads=T)
+    finally:
+        c.close()
+    assert best == 1 and abs(float(post.sum()) - 1.0) < 1e-3
+    n = int(g["n_reads"])
+    tot = []
+    for segs in cands:
+        md, _ = tdlib.build_model(segs, g["seq"], g["offs"], 0.05, 0.1)
+        md.update(threshold=0.0, minlen=16, dust=0)
+        res, _, _ = pyoracle.label_batch(pyoracle.OracleModel(md), g["seq"], g["offs"], 0.0, 16, 0, 4)
+        b = res["b_score"]
+        total = np.float32(0.0)
+        interval = n // T
+        for t in range(T):
+            lo, hi = t * interval, (n if t == T - 1 else (t + 1) * interval)
+            part = np.float32(0.0)
+            for x in b[lo:hi]:
+                part = np.float32(part + x)
+            total = np.float32(total + part)
+        tot.append(total)
+    lsum = pyoracle.lib().tdo_logsum
+    s_ = tot[0]
+    for x in tot[1:]:
+        s_ = np.float32(lsum(float(s_), float(x)))
+    norm = [np.float32(x - s_) for x in tot]
+    z = np.float32(-np.inf)
+    for x in norm:
+        z = np.float32(lsum(float(z), float(x)))
+    want = np.array([np.float32(np.exp(np.float64(np.float32(x - z)))) if np.isfinite(x - z) else np.float32(0) for x in norm], np.float32)
+    assert np.array_equal(post.view(np.uint32), want.view(np.uint32)), (post, want)
