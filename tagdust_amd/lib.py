@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtagdust_hip.so")
+LIB_PATH = os.environ.get("TD_LIB_PATH", os.path.join(HERE, "libtagdust_hip.so"))   # TD_LIB_PATH: A/B another build
 
 MODE_GET_LABEL = 1
 MODE_GET_PROB = 4
