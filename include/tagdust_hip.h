@@ -108,6 +108,9 @@ int td_model_upload(td_ctx* ctx, const td_model_desc* model);
 /* Options, set before td_model_upload:  "specialize" 1 = model-specialised kernel (default; env TD_SPECIALIZE),
  * 0 = the generic ahead-of-time kernel that reads the model from HBM. */
 int td_set_option(td_ctx* ctx, const char* name, int32_t value);
+/* Read a setting back: "specialize", or "spec_lsum_clamped" (1 when the loaded specialised kernel uses the clamped
+ * logsum: the clamp-free form is only selected while model parameters x read length bound every score difference). */
+int td_get_option(td_ctx* ctx, const char* name, int32_t* value);
 /* The HIP source td_model_upload would compile for this model (no GPU needed).  Returns its length; copies at
  * most cap-1 bytes + NUL into buf when buf != NULL. */
 int64_t td_spec_source(const td_model_desc* model, char* buf, int64_t cap);

@@ -6,6 +6,7 @@
 // with TD_FAIL (and a message in td_last_error) when HIP does.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cmath>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -64,6 +65,13 @@ struct td_ctx {
 	hipFunction_t spec_fn = nullptr;
 	std::vector<int32_t> m_n_hmm, m_n_col;
 	std::vector<float> m_trans;
+	// deep copy of the uploaded description (a batch with very long reads recompiles the kernel with the clamped logsum)
+	td_model_desc m_desc{};
+	std::vector<float> m_skip, m_eM, m_eI, m_sM, m_sI, m_A;
+	std::vector<int8_t> m_seg_type;
+	std::vector<int32_t> m_finger_len;
+	bool spec_oob = false;      // the loaded kernel uses the clamp-free logsum
+	float m_maxabs = 0.0f;      // largest |finite parameter|
 	TdSpecLayout slay{};
 	int spec_block = 256, spec_waves_per_cu = 8;
 
@@ -202,6 +210,31 @@ extern "C" void td_ctx_destroy(td_ctx* c)
 // ---------------------------------------------------------------------------------------------------------
 // model
 // ---------------------------------------------------------------------------------------------------------
+// Compile (or fetch from the cache) and load the model-specialised kernel.  lsum_oob selects the clamp-free logsum.
+static int load_spec_kernel(td_ctx* c, int lsum_oob)
+{
+	if (c->spec_mod) { HIPCHK(c, hipModuleUnload(c->spec_mod)); c->spec_mod = nullptr; }
+	c->spec_fn = nullptr; c->spec_ready = false;
+	std::vector<char> code;
+	std::string log;
+	if (td_spec_compile(&c->m_desc, code, log, lsum_oob) != TD_OK) return fail(c, "td_model_upload: specialised kernel did not compile: %.400s", log.c_str());
+	HIPCHK(c, hipModuleLoadData(&c->spec_mod, code.data()));
+	HIPCHK(c, hipModuleGetFunction(&c->spec_fn, c->spec_mod, "td_spec_kernel"));
+	c->spec_ready = true;
+	c->spec_oob = lsum_oob != 0;
+	return TD_OK;
+}
+
+// The clamp-free logsum of the specialised kernel turns |a - b| * 1000 into an LDS byte address that wraps at
+// |a - b| = 2^30 / 1000.  Every finite DP value is a sum of at most 2 parameters per position, and the posterior terms
+// add two such values, so 4 * max|parameter| * (L + 2) bounds every finite difference; 6 * keeps a margin.
+static bool spec_lsum_range_ok(const td_ctx* c, int lmax)
+{
+	double limit = 1.0e6;
+	if (const char* e = getenv("TD_SPEC_LSUM_LIMIT")) limit = atof(e);   // tests: force the switch to the clamped form
+	return 6.0 * (double)c->m_maxabs * ((double)lmax + 2.0) < limit;
+}
+
 extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 {
 	if (!c || !m) return fail(c, "td_model_upload: NULL argument");
@@ -292,18 +325,30 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 	if (c->spec_mod) { HIPCHK(c, hipModuleUnload(c->spec_mod)); c->spec_mod = nullptr; }
 	c->spec_fn = nullptr; c->spec_ready = false;
 	if (c->specialize) {
-		std::vector<char> code;
-		std::string log;
-		if (td_spec_compile(m, code, log) != TD_OK) return fail(c, "td_model_upload: specialised kernel did not compile: %.400s", log.c_str());
-		HIPCHK(c, hipModuleLoadData(&c->spec_mod, code.data()));
-		HIPCHK(c, hipModuleGetFunction(&c->spec_fn, c->spec_mod, "td_spec_kernel"));
-		c->spec_ready = true;
+		// keep what a later recompile needs
+		c->m_skip.assign(m->skip, m->skip + m->S);
+		c->m_seg_type.assign(m->seg_type, m->seg_type + m->S);
+		c->m_finger_len.assign(m->finger_len, m->finger_len + m->S);
+		c->m_eM.assign(m->eM, m->eM + (size_t)m->C * 5); c->m_eI.assign(m->eI, m->eI + (size_t)m->C * 5);
+		c->m_sM.assign(m->sM, m->sM + m->C); c->m_sI.assign(m->sI, m->sI + m->C);
+		c->m_A.assign(m->A, m->A + (size_t)m->H * m->H);
+		c->m_desc = *m;
+		c->m_desc.n_hmm = c->m_n_hmm.data(); c->m_desc.n_col = c->m_n_col.data(); c->m_desc.skip = c->m_skip.data();
+		c->m_desc.seg_type = c->m_seg_type.data(); c->m_desc.finger_len = c->m_finger_len.data();
+		c->m_desc.trans = c->m_trans.data(); c->m_desc.eM = c->m_eM.data(); c->m_desc.eI = c->m_eI.data();
+		c->m_desc.sM = c->m_sM.data(); c->m_desc.sI = c->m_sI.data(); c->m_desc.label = c->label.data(); c->m_desc.A = c->m_A.data();
+		float mx = 0.0f;
+		auto scan = [&](const float* v, size_t n) { for (size_t i = 0; i < n; i++) if (std::isfinite(v[i]) && fabsf(v[i]) > mx) mx = fabsf(v[i]); };
+		scan(m->trans, (size_t)m->C * 9); scan(m->eM, (size_t)m->C * 5); scan(m->eI, (size_t)m->C * 5);
+		scan(m->sM, m->C); scan(m->sI, m->C); scan(m->skip, m->S); scan(m->bg, 5);
+		c->m_maxabs = mx;
+		if (load_spec_kernel(c, td_spec_lsum_oob()) != TD_OK) return TD_FAIL;
 		c->spec_block = td_spec_block_threads();
 		// resident waves per CU: two LDS tables fit a CU; a 1024-thread workgroup fills it alone
 		{
 			const int wpb = c->spec_block / TD_WAVE;
 			int blocks_per_cu = 32 / wpb;             // 32 waves per CU
-			if (blocks_per_cu > 2) blocks_per_cu = 2; // two 62.8 KB tables per 160 KB of LDS
+			if (blocks_per_cu > 2) blocks_per_cu = 2; // two logsum tables (<= 66.5 KB each) per 160 KB of LDS
 			if (blocks_per_cu < 1) blocks_per_cu = 1;
 			c->spec_waves_per_cu = blocks_per_cu * wpb;
 		}
@@ -321,6 +366,14 @@ extern "C" int td_set_option(td_ctx* c, const char* name, int32_t value)
 		return TD_OK;
 	}
 	return fail(c, "td_set_option: unknown option %s", name);
+}
+
+extern "C" int td_get_option(td_ctx* c, const char* name, int32_t* value)
+{
+	if (!c || !name || !value) return TD_FAIL;
+	if (!strcmp(name, "specialize")) { *value = c->specialize; return TD_OK; }
+	if (!strcmp(name, "spec_lsum_clamped")) { *value = c->spec_ready && !c->spec_oob; return TD_OK; }
+	return fail(c, "td_get_option: unknown option %s", name);
 }
 
 extern "C" int td_set_params(td_ctx* c, float threshold, int32_t minlen, int32_t dust)
@@ -439,6 +492,9 @@ static int upload_common(td_ctx* c, const uint8_t* codes, const char* ascii, con
 	if (ensure(c, &c->d_out, &c->cap_out, (size_t)ol.total) != TD_OK) return TD_FAIL;
 	make_layout(c->lay, c->hdr.S, c->hdr.H, c->hdr.C, lmax, c->hdr.max_ncol);
 	int64_t slot_bytes = c->lay.slot_bytes;
+	if (c->spec_ready && c->spec_oob && !spec_lsum_range_ok(c, lmax)) {
+		if (load_spec_kernel(c, 0) != TD_OK) return TD_FAIL;   // reads this long need the clamped logsum (seconds, once)
+	}
 	if (c->spec_ready) {
 		td_model_desc md{};
 		md.S = c->hdr.S; md.H = c->hdr.H; md.C = c->hdr.C;

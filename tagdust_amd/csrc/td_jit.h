@@ -10,7 +10,8 @@ int td_spec_pure_last(const td_model_desc* m, int j, int col_off);
 int td_spec_rt_prefix(const td_model_desc* m, int j, int col_off, int8_t* base, float* hi, float* lo, float* nv);
 int td_spec_block_threads(void);
 int td_spec_min_waves(void);
-std::string td_spec_model_section(const td_model_desc* m);
-std::string td_spec_full_source(const td_model_desc* m);
+int td_spec_lsum_oob(void);      /* 1: clamp-free logsum (LDS out-of-range reads as 0), see td_spec_kernel.inc */
+std::string td_spec_model_section(const td_model_desc* m, int lsum_oob = -1);   /* lsum_oob < 0: td_spec_lsum_oob() */
+std::string td_spec_full_source(const td_model_desc* m, int lsum_oob = -1);
 void td_spec_layout(TdSpecLayout& L, const td_model_desc* m, int lmax);
-int td_spec_compile(const td_model_desc* m, std::vector<char>& code, std::string& log);
+int td_spec_compile(const td_model_desc* m, std::vector<char>& code, std::string& log, int lsum_oob = -1);

@@ -312,3 +312,25 @@ def test_read_without_valid_path_is_a_mismatch(ctx):
     keep = np.r_[0:35, 36:n_good + 1]
     assert np.array_equal(res["read_type"][keep], g["read_type"][:n_good])
     assert np.array_equal(_bits(res["f_score"][keep]), _bits(g["f_score"][:n_good]))
+
+
+def test_long_reads_switch_to_clamped_logsum(monkeypatch):
+    """The clamp-free logsum of the specialised kernel is only used while parameters x read length bound every score
+    difference below the point where its LDS byte address would wrap; beyond that td_batch_upload reloads the kernel
+    with the clamped form.  Forced here through the limit knob; results stay bit-exact either way."""
+    from tagdust_amd import TagdustHip
+    g = load_golden("c2_indel_varlen")
+    c = TagdustHip(0)
+    try:
+        c.set_option("specialize", 1)
+        res0, labels0, seq0 = _run(c, g)
+        assert c.get_option("spec_lsum_clamped") == 0
+        monkeypatch.setenv("TD_SPEC_LSUM_LIMIT", "1")
+        res1, labels1, seq1 = _run(c, g)
+        assert c.get_option("spec_lsum_clamped") == 1
+    finally:
+        c.close()
+    for k in ("b_score", "f_score", "r_score", "bar_prob", "mapq"):
+        assert np.array_equal(_bits(res0[k]), _bits(res1[k]))
+    assert np.array_equal(labels0, labels1) and np.array_equal(labels0, g["labels"])
+    assert np.array_equal(seq0, seq1) and np.array_equal(seq0, g["seq_after"])

@@ -23,6 +23,8 @@ def check(name="c3_b6_s_r_p", keep=False, outdir="/tmp/td_spec"):
     t0 = time.time()
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
            "--cuda-device-only", "-c", path, "-o", os.path.join(outdir, name + ".o"), "-Rpass-analysis=kernel-resource-usage"]
+    if os.environ.get("TD_SPEC_SLP", "0") == "0":
+        cmd += ["-fno-slp-vectorize"]      # as td_jit.hip compiles it
     if keep:
         cmd += ["-save-temps=obj"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
