@@ -114,6 +114,14 @@ int td_get_option(td_ctx* ctx, const char* name, int32_t* value);
 /* The HIP source td_model_upload would compile for this model (no GPU needed).  Returns its length; copies at
  * most cap-1 bytes + NUL into buf when buf != NULL. */
 int64_t td_spec_source(const td_model_desc* model, char* buf, int64_t cap);
+/* -ref artifact filter, match_to_reference() src/barcode_hmm.c:2478-2583 (runs between extraction and DUST in
+ * TD_MODE_GET_LABEL): string / s_index[n_seq+1] are struct fasta's fields as read_fasta() leaves them (io.c:1912-2001:
+ * per sequence one 'X' byte followed by the base codes); filter_error = param->filter_error (-fe);
+ * n_threads = param->num_threads -- the reference pairs reads in fours from the start of each thread's range and
+ * scores the up-to-3 left-over reads of a range with a different routine, which is reproduced.  A matching read gets
+ * read_type = (1-based sequence index << 8) | 5.  n_seq = 0 switches the filter off. */
+int td_set_artifacts(td_ctx* ctx, const uint8_t* string, const int32_t* s_index, int32_t n_seq,
+                     int32_t filter_error, int32_t n_threads);
 /* param->confidence_threshold in effect, param->minlen, param->dust (0 = off) */
 int td_set_params(td_ctx* ctx, float threshold, int32_t minlen, int32_t dust);
 

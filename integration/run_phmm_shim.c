@@ -10,7 +10,7 @@
  * writes the results back into struct read_info exactly where do_label_thread / do_probability_estimation leave
  * them (mapq, labels, read_type, barcode, fingerprint, seq/qual rewritten in place, bar_prob = 100).
  *
- * What the GPU path does not cover (the dead training modes, -ref artifact matching, -start/-end windows) is passed to
+ * What the GPU path does not cover (the dead training modes, -start/-end windows) is passed to
  * the reference's own CPU implementation, which the build recipe keeps available as ref_run_pHMM() (oracle/Makefile).
  */
 #include <stdio.h>
@@ -153,9 +153,9 @@ int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, s
 {
 	int i, k, status = kslOK;
 
-	/* not on the GPU path: training modes, artifact matching, -start/-end windows */
+	/* not on the GPU path: training modes, -start/-end windows */
 	if ((mode != MODE_GET_LABEL && mode != MODE_GET_PROB && mode != MODE_ARCH_COMP) || (mode == MODE_ARCH_COMP && !ab) ||
-	    reference_fasta || param->matchstart != -1 || param->matchend != -1)
+	    param->matchstart != -1 || param->matchend != -1)
 		return ref_run_pHMM(ab, mb, ri, param, reference_fasta, numseq, mode);
 	if (numseq <= 0) return kslOK;
 
@@ -167,6 +167,11 @@ int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, s
 	if (td_set_option(g_ctx, "specialize", 1) != TD_OK) goto ERROR;
 	if (upload_model(mb, param, 1) != TD_OK) goto ERROR;
 	if (td_set_params(g_ctx, param->confidence_threshold, param->minlen, param->dust) != TD_OK) goto ERROR;
+	/* -ref: match_to_reference (barcode_hmm.c:2349-2351) moves to the device; it only runs in label mode */
+	if (mode == MODE_GET_LABEL && reference_fasta && param->reference_fasta) {
+		if (td_set_artifacts(g_ctx, reference_fasta->string, reference_fasta->s_index, reference_fasta->numseq,
+		                     param->filter_error, param->num_threads) != TD_OK) goto ERROR;
+	} else if (td_set_artifacts(g_ctx, NULL, NULL, 0, 0, 1) != TD_OK) goto ERROR;
 
 	int64_t* offs = malloc(sizeof(int64_t) * ((size_t)numseq + 1));
 	offs[0] = 0;

@@ -33,6 +33,10 @@ class _Params(C.Structure):
     _fields_ = [("threshold", C.c_float), ("minlen", C.c_int32), ("dust", C.c_int32)]
 
 
+class _Artifacts(C.Structure):
+    _fields_ = [("string", C.c_void_p), ("s_index", C.c_void_p), ("n_seq", C.c_int32), ("filter_error", C.c_int32)]
+
+
 RESULT_DTYPE = np.dtype([
     ("b_score", "<f4"), ("f_score", "<f4"), ("r_score", "<f4"), ("bar_prob", "<f4"),
     ("Q", "<f4"), ("read_type", "<i4"), ("barcode", "<i4"), ("fingerprint", "<i4"),
@@ -62,6 +66,9 @@ def lib():
         _lib.tdo_label_batch.restype = C.c_int
         _lib.tdo_label_batch.argtypes = [C.POINTER(_Model), C.POINTER(_Params), C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        _lib.tdo_label_batch_art.restype = C.c_int
+        _lib.tdo_label_batch_art.argtypes = [C.POINTER(_Model), C.POINTER(_Params), C.POINTER(_Artifacts), C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         _lib.tdo_init_logsum()
     return _lib
 
@@ -106,8 +113,10 @@ class OracleModel:
         self.c = m
 
 
-def label_batch(model, seqs, offs, threshold, minlen=16, dust=100, n_threads=1):
+def label_batch(model, seqs, offs, threshold, minlen=16, dust=100, n_threads=1, artifacts=None):
     """Run the oracle over a batch.  seqs: uint8 codes (0..4) concatenated; offs: int64 [n+1].
+    artifacts: None or (string uint8, s_index int32 [n_seq+1], filter_error) -- struct fasta as read_fasta() leaves
+    it; matching depends on n_threads (match_to_reference pairs reads in fours per thread range).
     Returns (results structured array, labels int8 laid out at offs[i]+i with len+1 entries,
     seq_after uint8)."""
     L = lib()
@@ -117,8 +126,13 @@ def label_batch(model, seqs, offs, threshold, minlen=16, dust=100, n_threads=1):
     labels = np.zeros(int(offs[-1]) + n, dtype=np.int8)
     res = np.zeros(n, dtype=RESULT_DTYPE)
     p = _Params(float(threshold), int(minlen), int(dust))
-    rc = L.tdo_label_batch(C.byref(model.c), C.byref(p), int(n_threads), seq_after.ctypes.data,
-                           offs.ctypes.data, n, labels.ctypes.data, res.ctypes.data)
+    art = None
+    if artifacts is not None:
+        a_str = np.ascontiguousarray(artifacts[0], dtype=np.uint8)
+        a_idx = np.ascontiguousarray(artifacts[1], dtype=np.int32)
+        art = C.byref(_Artifacts(a_str.ctypes.data, a_idx.ctypes.data, len(a_idx) - 1, int(artifacts[2])))
+    rc = L.tdo_label_batch_art(C.byref(model.c), C.byref(p), art, int(n_threads), seq_after.ctypes.data,
+                               offs.ctypes.data, n, labels.ctypes.data, res.ctypes.data)
     if rc != 0:
         raise RuntimeError("tdo_label_batch failed (%d)" % rc)
     return res, labels, seq_after

@@ -174,9 +174,20 @@ int main(int argc, char* argv[])
 		memcpy(lab[i], ri[i]->labels, len + 1);
 	}
 
-	param->num_threads = 1;
+	/* -ref <fasta>: artifact matching (match_to_reference, barcode_hmm.c:2478-2583) runs inside run_pHMM between
+	   extraction and DUST; it pairs reads in fours from the start of each thread's range, so the thread count
+	   matters (REF_DUMP_THREADS, default 1).  The fasta is loaded as hmm_controller_multiple does (:209-216). */
+	struct fasta* reference_fasta = 0;
+	int n_threads = 1;
+	if(getenv("REF_DUMP_THREADS")) n_threads = atoi(getenv("REF_DUMP_THREADS"));
+	if(param->reference_fasta){
+		reference_fasta = get_fasta(reference_fasta, param->reference_fasta);
+		reference_fasta->mer_hash = malloc(sizeof(int) * reference_fasta->numseq);
+		for(i = 0; i < reference_fasta->numseq; i++) reference_fasta->mer_hash[i] = 0;
+	}
+	param->num_threads = n_threads;
 	param->confidence_threshold = threshold;
-	if(run_pHMM(0, mb, ri, param, 0, numseq, MODE_GET_LABEL) != kslOK){ fprintf(stderr, "run_pHMM failed\n"); return 1; }
+	if(run_pHMM(0, mb, ri, param, reference_fasta, numseq, MODE_GET_LABEL) != kslOK){ fprintf(stderr, "run_pHMM failed\n"); return 1; }
 
 	for(i = 0; i < numseq; i++){
 		int len = ri[i]->len;
@@ -197,6 +208,15 @@ int main(int argc, char* argv[])
 		w_i32(ri[i]->barcode);
 		w_i32(ri[i]->fingerprint);
 		w_bytes(ri[i]->seq, len);
+	}
+	/* ---- optional trailer: the artifact sequences as read_fasta() left them ---- */
+	if(reference_fasta){
+		w_bytes("ARTF", 4);
+		w_i32(reference_fasta->numseq);
+		w_i32(param->filter_error);
+		w_i32(n_threads);
+		for(i = 0; i <= reference_fasta->numseq; i++) w_i32(reference_fasta->s_index[i]);
+		w_bytes((char*)reference_fasta->string, reference_fasta->s_index[reference_fasta->numseq]);
 	}
 	fclose(out);
 	fprintf(stderr, "ref_dump: %d reads, S=%d H=%d C=%d threshold=%f avg_len=%d -> %s\n",

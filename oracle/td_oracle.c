@@ -522,6 +522,119 @@ int tdo_dust(const uint8_t* seq, int len, int dust_cut)
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * artifact matching: bmp_single misc.c:718-765, bpm_check_error misc.c:581-640, reverse_complement
+ * misc.c:827-851, match_to_reference barcode_hmm.c:2478-2583
+ * ---------------------------------------------------------------------------------------------- */
+static int bmp_single_(const uint8_t* t, const uint8_t* p, int n, int m)
+{
+	uint64_t VP, VN, D0, HN, HP, X, MASK, B[4] = { 0, 0, 0, 0 };
+	int64_t diff;
+	int k;
+	if (m > 63) m = 63;
+	diff = m;
+	k = m;
+	for (int i = 0; i < m; i++)
+		if (p[i] != 65) B[p[i] & 0x3u] |= UINT64_C(1) << i;
+	VP = (UINT64_C(1) << m) - 1;
+	VN = 0;
+	m--;
+	MASK = UINT64_C(1) << m;
+	for (int i = 0; i < n; i++) {
+		X = B[t[i] & 0x3u] | VN;
+		D0 = ((VP + (X & VP)) ^ VP) | X;
+		HN = VP & D0;
+		HP = VN | ~(VP | D0);
+		X = HP << 1;
+		VN = X & D0;
+		VP = (HN << 1) | ~(X | D0);
+		diff += (HP & MASK) ? 1 : 0;
+		diff -= (HN & MASK) ? 1 : 0;
+		if (diff < k) k = (int)diff;
+	}
+	return k;
+}
+
+/* The reference shifts by counts >= 64 (reads longer than 64) and by -1 (no usable base); both are taken modulo 64 as
+ * the x86-64 shift instructions the reference's build emits do. */
+static int bpm_check_error_(const uint8_t* t, const uint8_t* p, int n, int m)
+{
+	uint64_t VP, VN, D0, HN, HP, X, MASK, diff, k, B[4] = { 0, 0, 0, 0 };
+	int new_len = 0;
+	diff = (uint64_t)m;
+	for (int i = 0; i < m; i++)
+		if (p[i] != 65) { B[p[i] & 0x3] |= UINT64_C(1) << (i & 63); new_len++; }
+	if (new_len > 31) new_len = 31;
+	m = new_len;
+	k = (uint64_t)new_len;
+	VP = UINT64_MAX;
+	VN = 0;
+	m--;
+	MASK = UINT64_C(1) << (m & 63);
+	for (int i = 0; i < n; i++) {
+		X = B[t[i] & 0x3] | VN;
+		D0 = ((VP + (X & VP)) ^ VP) | X;
+		HN = VP & D0;
+		HP = VN | ~(VP | D0);
+		X = HP << 1;
+		VN = X & D0;
+		VP = (HN << 1) | ~(X | D0);
+		diff += (HP & MASK) >> (m & 63);
+		diff -= (HN & MASK) >> (m & 63);
+		if (diff < k) k = diff;
+	}
+	return (int)k;
+}
+
+static void revcomp_(uint8_t* p, int len)
+{
+	static const uint8_t rev[5] = { 3, 2, 1, 0, 4 }; /* rev_nuc_code, nuc_code.c:68-72 */
+	for (int i = 0, j = len - 1; i < j; i++, j--) { const uint8_t x = p[i]; p[i] = p[j]; p[j] = x; }
+	for (int i = 0; i < len; i++) if (p[i] != 65) p[i] = rev[p[i] > 4 ? 4 : p[i]];
+}
+
+void tdo_match_artifacts(const tdo_artifacts* a, uint8_t* seqs, const int64_t* offs, tdo_result* res,
+                         int64_t start, int64_t end)
+{
+	int64_t i;
+	for (i = start; i <= end - 4; i += 4) {
+		int errors[4], id[4];
+		for (int c = 0; c < 4; c++) { errors[c] = 100000; id[c] = 0; }
+		for (int j = 0; j < a->n_seq; j++) {
+			const uint8_t* t = a->string + a->s_index[j];
+			const int n = a->s_index[j + 1] - a->s_index[j];
+			for (int strand = 0; strand < 2; strand++) {
+				for (int c = 0; c < 4; c++) {
+					uint8_t* q = seqs + offs[i + c];
+					const int len = (int)(offs[i + c + 1] - offs[i + c]);
+					if (strand) revcomp_(q, len);
+					const int e = len > 0 ? bmp_single_(t, q, n, len) : n; /* validate_bpm_sse, misc.c:776-795 */
+					if (strand) revcomp_(q, len);
+					if (e < errors[c]) { errors[c] = e; id[c] = j + 1; }
+				}
+			}
+		}
+		for (int c = 0; c < 4; c++)
+			if (errors[c] <= a->filter_error && res[i + c].read_type == TDO_EXTRACT_SUCCESS)
+				res[i + c].read_type = (id[c] << 8) | TDO_FAIL_MATCHES_ARTIFACTS;
+	}
+	for (; i < end; i++) {
+		uint8_t* q = seqs + offs[i];
+		const int len = (int)(offs[i + 1] - offs[i]);
+		int hit = 0;
+		for (int j = 0; j < a->n_seq && !hit; j++) {
+			const uint8_t* t = a->string + a->s_index[j];
+			const int n = a->s_index[j + 1] - a->s_index[j];
+			if (bpm_check_error_(t, q, n, len) <= a->filter_error) { hit = j + 1; break; }
+			revcomp_(q, len);
+			const int e = bpm_check_error_(t, q, n, len);
+			revcomp_(q, len);
+			if (e <= a->filter_error) { hit = j + 1; break; }
+		}
+		if (hit && res[i].read_type == TDO_EXTRACT_SUCCESS) res[i].read_type = (hit << 8) | TDO_FAIL_MATCHES_ARTIFACTS;
+	}
+}
+
+/* ------------------------------------------------------------------------------------------------
  * do_label_thread for one read, barcode_hmm.c:2269-2360
  * ---------------------------------------------------------------------------------------------- */
 void tdo_label_read(const tdo_model* m, const tdo_params* p, tdo_workspace* ws,
@@ -541,7 +654,7 @@ void tdo_label_read(const tdo_model* m, const tdo_params* p, tdo_workspace* ws,
  * run_pHMM(MODE_GET_LABEL) analogue, barcode_hmm.c:1895-2029
  * ---------------------------------------------------------------------------------------------- */
 struct batch_job {
-	const tdo_model* m; const tdo_params* p;
+	const tdo_model* m; const tdo_params* p; const tdo_artifacts* art;
 	uint8_t* seqs; const int64_t* offs; int8_t* labels; tdo_result* res;
 	int64_t start, end; int max_len; int status;
 };
@@ -551,9 +664,19 @@ static void* batch_worker(void* arg)
 	struct batch_job* jb = (struct batch_job*)arg;
 	tdo_workspace* ws = tdo_workspace_new(jb->m, jb->max_len);
 	if (!ws) { jb->status = 1; return NULL; }
+	/* do_label_thread, :2286-2357: label + extract every read of the range, then artifacts, then DUST */
+	tdo_params nodust = *jb->p;
+	nodust.dust = 0;
 	for (int64_t i = jb->start; i < jb->end; i++) {
 		const int len = (int)(jb->offs[i + 1] - jb->offs[i]);
-		tdo_label_read(jb->m, jb->p, ws, jb->seqs + jb->offs[i], NULL, len, jb->labels + jb->offs[i] + i, &jb->res[i]);
+		tdo_label_read(jb->m, &nodust, ws, jb->seqs + jb->offs[i], NULL, len, jb->labels + jb->offs[i] + i, &jb->res[i]);
+	}
+	if (jb->art && jb->art->n_seq > 0) tdo_match_artifacts(jb->art, jb->seqs, jb->offs, jb->res, jb->start, jb->end);
+	if (jb->p->dust) {
+		for (int64_t i = jb->start; i < jb->end; i++) {
+			const int len = (int)(jb->offs[i + 1] - jb->offs[i]);
+			if (tdo_dust(jb->seqs + jb->offs[i], len, jb->p->dust)) jb->res[i].read_type = TDO_FAIL_LOW_COMPLEXITY;
+		}
 	}
 	tdo_workspace_free(ws);
 	jb->status = 0;
@@ -562,6 +685,12 @@ static void* batch_worker(void* arg)
 
 int tdo_label_batch(const tdo_model* m, const tdo_params* p, int n_threads,
                     uint8_t* seqs, const int64_t* offs, int64_t n_reads, int8_t* labels, tdo_result* res)
+{
+	return tdo_label_batch_art(m, p, NULL, n_threads, seqs, offs, n_reads, labels, res);
+}
+
+int tdo_label_batch_art(const tdo_model* m, const tdo_params* p, const tdo_artifacts* art, int n_threads,
+                        uint8_t* seqs, const int64_t* offs, int64_t n_reads, int8_t* labels, tdo_result* res)
 {
 	if (!g_logsum_ready) tdo_init_logsum();
 	if (n_threads < 1) n_threads = 1;
@@ -577,7 +706,7 @@ int tdo_label_batch(const tdo_model* m, const tdo_params* p, int n_threads,
 	const int64_t interval = n_reads / n_threads;
 	int rc = 0;
 	for (int t = 0; t < n_threads; t++) {
-		jobs[t] = (struct batch_job){ m, p, seqs, offs, labels, res, t * interval,
+		jobs[t] = (struct batch_job){ m, p, art, seqs, offs, labels, res, t * interval,
 		                              (t == n_threads - 1) ? n_reads : (t + 1) * interval, max_len, 0 };
 		if (pthread_create(&th[t], NULL, batch_worker, &jobs[t])) { jobs[t].status = 2; }
 	}

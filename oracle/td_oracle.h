@@ -99,6 +99,22 @@ void  tdo_extract(const tdo_model* m, const tdo_params* p, uint8_t* seq, uint8_t
 /* dust_sequences, barcode_hmm.c:2407-2467 (one read); returns 1 if low complexity */
 int   tdo_dust(const uint8_t* seq, int len, int dust_cut);
 
+/* -ref artifacts: struct fasta as read_fasta() leaves it (io.c:1912-2001): per sequence one 'X' byte followed by the
+ * base codes, s_index[n_seq+1] (sequence j = string[s_index[j] .. s_index[j+1]), the 'X' included). */
+typedef struct tdo_artifacts {
+	const uint8_t* string;
+	const int32_t* s_index;
+	int32_t n_seq;
+	int32_t filter_error;      /* param->filter_error */
+} tdo_artifacts;
+
+/* match_to_reference(), barcode_hmm.c:2478-2583, over one thread's range [start, end) of already extracted reads:
+ * reads are taken in fours from `start` (bmp_single, misc.c:718-765: best hit over all sequences and both strands),
+ * the up-to-3 left-over reads go through bpm_check_error (misc.c:581-640: first hit).  seqs are rewritten and restored
+ * by the in-place reverse complement exactly as in the reference. */
+void  tdo_match_artifacts(const tdo_artifacts* a, uint8_t* seqs, const int64_t* offs, tdo_result* res,
+                          int64_t start, int64_t end);
+
 /* whole per-read path of do_label_thread (barcode_hmm.c:2269-2360) for one read */
 void  tdo_label_read(const tdo_model* m, const tdo_params* p, tdo_workspace* ws,
                      uint8_t* seq, uint8_t* qual, int len, int8_t* labels, tdo_result* res);
@@ -108,6 +124,10 @@ void  tdo_label_read(const tdo_model* m, const tdo_params* p, tdo_workspace* ws,
 int   tdo_label_batch(const tdo_model* m, const tdo_params* p, int n_threads,
                       uint8_t* seqs, const int64_t* offs, int64_t n_reads,
                       int8_t* labels, tdo_result* res);
+/* the same with artifact matching between extraction and DUST (do_label_thread :2349-2355); art may be NULL */
+int   tdo_label_batch_art(const tdo_model* m, const tdo_params* p, const tdo_artifacts* art, int n_threads,
+                          uint8_t* seqs, const int64_t* offs, int64_t n_reads,
+                          int8_t* labels, tdo_result* res);
 
 #ifdef __cplusplus
 }

@@ -87,6 +87,10 @@ struct td_ctx {
 	std::vector<int64_t> pos_of;     // pos_of[i] = position of read i in the length-sorted device order
 	uint32_t* d_packed = nullptr; size_t cap_packed = 0;
 	int32_t* d_lens = nullptr;    size_t cap_lens = 0;
+	// -ref artifact filter
+	uint8_t* d_art_text = nullptr; int32_t* d_art_index = nullptr;
+	uint8_t* d_art_left = nullptr; size_t cap_art_left = 0;
+	int32_t art_n = 0, art_fe = 0, art_threads = 1;
 	uint8_t* d_out = nullptr;     size_t cap_out = 0;   // all per-read outputs in one allocation
 	uint8_t* d_ws = nullptr;      size_t cap_ws = 0;
 	TdWsLayout lay{};
@@ -198,7 +202,7 @@ extern "C" void td_ctx_destroy(td_ctx* c)
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	void* bufs[] = { c->d_hdr, c->d_cols, c->d_hinfo, c->d_pred_off, c->d_pred_idx, c->d_logsum, c->d_counters,
-	                 c->d_packed, c->d_lens, c->d_out, c->d_ws };
+	                 c->d_packed, c->d_lens, c->d_out, c->d_ws, c->d_art_text, c->d_art_index, c->d_art_left };
 	for (void* p : bufs) if (p) (void)hipFree(p);
 	if (c->spec_mod) (void)hipModuleUnload(c->spec_mod);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -374,6 +378,28 @@ extern "C" int td_get_option(td_ctx* c, const char* name, int32_t* value)
 	if (!strcmp(name, "specialize")) { *value = c->specialize; return TD_OK; }
 	if (!strcmp(name, "spec_lsum_clamped")) { *value = c->spec_ready && !c->spec_oob; return TD_OK; }
 	return fail(c, "td_get_option: unknown option %s", name);
+}
+
+extern "C" int td_set_artifacts(td_ctx* c, const uint8_t* string, const int32_t* s_index, int32_t n_seq,
+                                int32_t filter_error, int32_t n_threads)
+{
+	if (!c) return TD_FAIL;
+	HIPCHK(c, hipSetDevice(c->device));
+	if (c->d_art_text) { HIPCHK(c, hipFree(c->d_art_text)); c->d_art_text = nullptr; }
+	if (c->d_art_index) { HIPCHK(c, hipFree(c->d_art_index)); c->d_art_index = nullptr; }
+	c->art_n = 0;
+	if (n_seq <= 0) return TD_OK;
+	if (!string || !s_index) return fail(c, "td_set_artifacts: null argument");
+	if (n_threads < 1) return fail(c, "td_set_artifacts: n_threads = %d", n_threads);
+	for (int32_t j = 0; j < n_seq; j++)
+		if (s_index[j + 1] < s_index[j] || s_index[j] < 0) return fail(c, "td_set_artifacts: s_index is not ascending at %d", j);
+	const size_t bytes = (size_t)s_index[n_seq];
+	HIPCHK(c, hipMalloc((void**)&c->d_art_text, bytes ? bytes : 1));
+	HIPCHK(c, hipMalloc((void**)&c->d_art_index, sizeof(int32_t) * ((size_t)n_seq + 1)));
+	if (bytes) HIPCHK(c, hipMemcpy(c->d_art_text, string, bytes, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(c->d_art_index, s_index, sizeof(int32_t) * ((size_t)n_seq + 1), hipMemcpyHostToDevice));
+	c->art_n = n_seq; c->art_fe = filter_error; c->art_threads = n_threads;
+	return TD_OK;
 }
 
 extern "C" int td_set_params(td_ctx* c, float threshold, int32_t minlen, int32_t dust)
@@ -553,6 +579,21 @@ extern "C" int td_run(td_ctx* c, int mode)
 	ka.out_keep = (uint32_t*)(c->d_out + ol.keep); ka.out_labels = (int8_t*)(c->d_out + ol.labels);
 	ka.counters = c->d_counters;
 	ka.ws = c->d_ws; ka.lay = c->lay;
+	if (c->art_n > 0 && mode == TD_MODE_GET_LABEL) {
+		// match_to_reference takes the reads of each thread range [t*interval, ...) in fours and gives the
+		// (range length mod 4) left-over reads to another routine (barcode_hmm.c:2495-2575, ranges :1911-1922)
+		const int64_t n = c->n_reads, T = c->art_threads, interval = n / T;
+		std::vector<uint8_t> left((size_t)c->n_tiles * TD_WAVE, 0);
+		for (int64_t t = 0; t < T; t++) {
+			const int64_t start = t * interval, end = (t == T - 1) ? n : (t + 1) * interval;
+			for (int64_t i = start + (end - start) / 4 * 4; i < end; i++) left[(size_t)c->pos_of[(size_t)i]] = 1;
+		}
+		if (ensure(c, &c->d_art_left, &c->cap_art_left, left.size()) != TD_OK) return TD_FAIL;
+		HIPCHK(c, hipMemcpyAsync(c->d_art_left, left.data(), left.size(), hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));   // `left` goes out of scope
+		ka.art_text = c->d_art_text; ka.art_index = c->d_art_index; ka.art_left = c->d_art_left;
+		ka.art_n = c->art_n; ka.art_fe = c->art_fe;
+	}
 	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
 	if (c->spec_ready) {
 		TdSpecArgs sa{};
@@ -562,6 +603,7 @@ extern "C" int td_run(td_ctx* c, int mode)
 		sa.out_f = ka.out_f; sa.out_b = ka.out_b; sa.out_r = ka.out_r; sa.out_bar = ka.out_bar; sa.out_q = ka.out_q;
 		sa.out_type = ka.out_type; sa.out_barcode = ka.out_barcode; sa.out_finger = ka.out_finger;
 		sa.out_keep = ka.out_keep; sa.out_labels = ka.out_labels; sa.counters = ka.counters;
+		sa.art_text = ka.art_text; sa.art_index = ka.art_index; sa.art_left = ka.art_left; sa.art_n = ka.art_n; sa.art_fe = ka.art_fe;
 		sa.ws = ka.ws; sa.lay = c->slay;
 		size_t sz = sizeof sa;
 		void* cfg[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &sa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END };

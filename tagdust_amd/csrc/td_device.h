@@ -90,6 +90,11 @@ struct TdKernelArgs {
 	uint32_t* __restrict__ out_keep;       // [n_tiles][nw1][64]  bit k of read = position k is kept (label is an R segment)
 	int8_t*  __restrict__ out_labels;      // [n_tiles][lmax+1][64]
 	unsigned long long* __restrict__ counters; // [TD_NUM_COUNTERS]
+	// -ref artifact filter (td_artifact.inc); art_n == 0: off
+	const uint8_t*  __restrict__ art_text;  // struct fasta ->string as read_fasta() leaves it
+	const int32_t*  __restrict__ art_index; // [art_n + 1]
+	const uint8_t*  __restrict__ art_left;  // [n_tiles*64] 1 = left-over read of its thread range (bpm_check_error path)
+	int32_t art_n, art_fe;
 	// workspace
 	uint8_t* __restrict__ ws;
 	TdWsLayout lay;
@@ -131,6 +136,11 @@ struct TdSpecArgs {
 	uint32_t* __restrict__ out_keep;
 	int8_t*  __restrict__ out_labels;
 	unsigned long long* __restrict__ counters;
+	// -ref artifact filter (td_artifact.inc); art_n == 0: off
+	const uint8_t*  __restrict__ art_text;  // struct fasta ->string as read_fasta() leaves it
+	const int32_t*  __restrict__ art_index; // [art_n + 1]
+	const uint8_t*  __restrict__ art_left;  // [n_tiles*64] 1 = left-over read of its thread range (bpm_check_error path)
+	int32_t art_n, art_fe;
 	uint8_t* __restrict__ ws;
 	TdSpecLayout lay;
 };

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "td_device.h"
+#include "td_artifact.inc"
 
 #define TD_BLOCK 256                 // 4 waves share one LDS copy of the logsum table
 #define TD_WAVES_PER_BLOCK (TD_BLOCK / TD_WAVE)
@@ -40,6 +41,7 @@
 #define OUT_ARCH_MISMATCH 1
 #define OUT_TOO_SHORT 2
 #define OUT_BAR_FINGER_NOT_FOUND 3
+#define OUT_MATCHES_ARTIFACTS 5
 #define OUT_LOW_COMPLEXITY 6
 #define N_OUTCOME_SLOTS 8
 
@@ -721,6 +723,16 @@ __global__ __launch_bounds__(TD_BLOCK, 2) void td_decode_kernel(const TdKernelAr
 			}
 			// keep mask = positions whose byte the reference leaves untouched; all ones unless make_extracted_read ran
 			if (!extracted) for (int k = 0; k < nw1; k++) keep[k * TD_WAVE + lane] = 0xFFFFFFFFu;
+
+			// ---- match_to_reference, :2478-2583 (td_artifact.inc) ----
+			if (ka.art_n > 0) {
+				const uint8_t* cd = codes;
+				auto sq = [&](int kk) -> int {
+					return ((keep[(kk >> 5) * TD_WAVE + lane] >> (kk & 31)) & 1u) ? (int)cd[(kk + 1) * TD_WAVE + lane] : 65;
+				};
+				const int id = td_art_match(sq, len, tmax, ka.art_left[rid] != 0, ka.art_text, ka.art_index, ka.art_n, ka.art_fe);
+				if (id > 0 && read_type == OUT_SUCCESS) read_type = (id << 8) | OUT_MATCHES_ARTIFACTS;
+			}
 
 			// ---- dust_sequences, :2407-2467, on the rewritten sequence ----
 			if (ka.dust && len >= 1) {

@@ -19,7 +19,7 @@ NUM_COUNTERS = NUM_OUTCOME_SLOTS + NUM_BARCODE_BINS
 ABI_SYMBOLS = [
     "td_ctx_create", "td_ctx_destroy", "td_last_error", "td_logsum_table", "td_model_upload", "td_set_params",
     "td_batch_upload", "td_batch_upload_ascii", "td_run", "td_sync", "td_batch_download", "td_counts_reset",
-    "td_counts_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_batch_info", "td_set_option", "td_get_option", "td_spec_source",
+    "td_counts_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_batch_info", "td_set_option", "td_get_option", "td_set_artifacts", "td_spec_source",
 ]
 IO_ABI_SYMBOLS = ["td_reads_parse", "td_reads_free", "td_writer_open", "td_writer_write", "td_writer_close"]
 MODEL_ABI_SYMBOLS = ["td_arch_parse", "td_arch_free", "td_sequence_stats", "td_model_build", "td_model_tables_free",
@@ -83,6 +83,8 @@ def load_library():
     lib.td_model_upload.argtypes = [C.c_void_p, C.POINTER(_ModelDesc)]
     lib.td_set_params.argtypes = [C.c_void_p, C.c_float, C.c_int32, C.c_int32]
     lib.td_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+    if hasattr(lib, "td_set_artifacts"):
+        lib.td_set_artifacts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     if hasattr(lib, "td_get_option"):   # absent from older builds loaded through TD_LIB_PATH for A/B runs
         lib.td_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]
     lib.td_spec_source.argtypes = [C.POINTER(_ModelDesc), C.c_char_p, C.c_int64]
@@ -370,6 +372,15 @@ class TagdustHip:
 
     def set_option(self, name, value):
         self._chk(self.lib.td_set_option(self.h, name.encode(), int(value)))
+
+    def set_artifacts(self, string=None, s_index=None, filter_error=2, n_threads=1):
+        """-ref artifact filter (struct fasta's string / s_index); None switches it off."""
+        if string is None:
+            self._chk(self.lib.td_set_artifacts(self.h, None, None, 0, 0, 1))
+            return
+        a = np.ascontiguousarray(string, dtype=np.uint8)
+        ix = np.ascontiguousarray(s_index, dtype=np.int32)
+        self._chk(self.lib.td_set_artifacts(self.h, a.ctypes.data, ix.ctypes.data, len(ix) - 1, int(filter_error), int(n_threads)))
 
     def get_option(self, name):
         v = C.c_int32(0)

@@ -22,6 +22,13 @@ def load_golden(name):
     return {k: z[k] for k in z.files}
 
 
+def golden_artifacts(g):
+    """(string, s_index, filter_error, n_threads) of a fixture that was run with -ref, else None."""
+    if "art_n" not in g:
+        return None
+    return g["art_string"], g["art_index"], int(g["art_filter_error"]), int(g["art_threads"])
+
+
 @pytest.fixture(params=GOLDEN_NAMES)
 def golden(request):
     d = load_golden(request.param)

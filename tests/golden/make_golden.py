@@ -112,6 +112,12 @@ def parse_dump(path):
         mapq[i] = r.arr("<f4", 1)[0]
         ints[i] = r.arr("<i4", 3)
         seq_after.append(r.arr("u1", ln))
+    if r.o < len(r.b):  # optional trailer: -ref artifact sequences as read_fasta() left them
+        assert r.arr("S4", 1)[0] == b"ARTF"
+        n_art, fe, nt = r.arr("<i4", 3)
+        d["art_n"], d["art_filter_error"], d["art_threads"] = n_art, fe, nt
+        d["art_index"] = r.arr("<i4", n_art + 1)
+        d["art_string"] = r.arr("u1", int(d["art_index"][-1]))
     assert r.o == len(r.b), (r.o, len(r.b))
     d["n_reads"] = n
     d["lens"] = lens
@@ -284,6 +290,36 @@ def scenarios(tmp):
         synth_reads(fq, 160, 80, bars, 0, "CTGCA", "", seed=19)
         return fq, ["-seed", "42", "-1", "B:" + ",".join(bars), "-2", "P:CTGCA", "-3", "G:G", "-4", "R:N"]
     sc["b_intp_g_r"] = int_p
+
+    def artifacts():  # -ref: artifact matching between extraction and DUST, 3 threads (4-groups + left-over reads)
+        fq = os.path.join(tmp, "art.fq")
+        fa = os.path.join(tmp, "art.fa")
+        rng = np.random.RandomState(23)
+        arts = ["".join("ACGT"[k] for k in rng.randint(0, 4, L)) for L in (70, 48, 95)]
+        with open(fa, "w") as fh:
+            for k, a in enumerate(arts):
+                fh.write(">artifact %d\n%s\n" % (k + 1, "\n".join(a[x:x + 40] for x in range(0, len(a), 40))))
+        bars = read_tags(os.path.join(dev, "EDITTAG_4nt_ed_2.txt"), 4)
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+        with open(fq, "w") as fh:
+            for i in range(203):  # 203 reads over 3 threads: ranges of 67, 67, 69 -> 3 + 3 + 1 left-over reads
+                b = bars[rng.randint(len(bars))]
+                L = int(rng.randint(36, 60))
+                u = rng.random_sample()
+                if u < 0.45:      # a window of an artifact, either strand, a few substitutions
+                    a = arts[rng.randint(len(arts))]
+                    st = int(rng.randint(0, max(len(a) - L, 1)))
+                    ins = a[st:st + L]
+                    if rng.random_sample() < 0.5:
+                        ins = "".join(comp[ch] for ch in reversed(ins))
+                    ins = mutate(rng, ins, 0.03 if u < 0.3 else 0.12, 0.02)
+                else:
+                    ins = "".join("ACGT"[k] for k in rng.randint(0, 4, L))
+                s_ = b + ins
+                fh.write("@READ%d\n%s\n+\n%s\n" % (i, s_, "I" * len(s_)))
+        os.environ["REF_DUMP_THREADS"] = "3"
+        return fq, ["-seed", "42", "-ref", fa, "-fe", "9", "-1", "B:" + ",".join(bars), "-2", "R:N"]
+    sc["artifacts_b_r"] = artifacts
     return sc
 
 
@@ -297,8 +333,9 @@ def main():
             dump = os.path.join(tmp, name + ".bin")
             cmd = [os.path.join(RBIN, "ref_dump_rtest"), dump] + args + [fq, "-o", os.path.join(tmp, name + "_out")]
             log = run(cmd, cwd=tmp)
+            os.environ.pop("REF_DUMP_THREADS", None)
             d = parse_dump(dump)
-            d["cmdline"] = np.array(" ".join(args))
+            d["cmdline"] = np.array(" ".join(a if not a.startswith(tmp) else os.path.basename(a) for a in args))
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
             kb = os.path.getsize(os.path.join(HERE, name + ".npz")) / 1024
             vals, cnt = np.unique(d["read_type"], return_counts=True)

@@ -138,3 +138,31 @@ def test_bar_read_test_paired_scenarios_gold(tmp_path, barnum, gold):
     open(os.path.join(d, "combo_arch.txt"), "w").write(arch)
     _run("tagdust_hip_rtest", ["-seed", "42", "-sim_numseq", "1", "r1.fq", "r2.fq", "-arch", "combo_arch.txt", "-o", "paired_tagdust"], d)
     assert gold in _eval(d, "paired_tagdust_*READ1.fq", "paired_tagdust")
+
+
+@pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("threads", [1, 3])
+def test_reference_cli_with_artifact_filter(tmp_path, threads):
+    """-ref: match_to_reference runs on the device (td_set_artifacts); the thread count decides which reads are the
+    left-over reads of a range, so both binaries get the same -t."""
+    g = load_golden("artifacts_b_r")
+    fq, fa = str(tmp_path / "in.fq"), str(tmp_path / "art.fa")
+    _write_fastq(g, fq)
+    ix, st = g["art_index"], g["art_string"]
+    with open(fa, "w") as fh:
+        for j in range(int(g["art_n"])):
+            fh.write(">artifact_%d\n%s\n" % (j + 1, "".join("ACGT"[c & 3] for c in st[ix[j] + 1:ix[j + 1]])))
+    args = str(g["cmdline"]).split()
+    args[args.index("-ref") + 1] = fa
+    args += ["-t", str(threads)]
+    _run("tagdust_rtest", args + [fq, "-o", "cpu"], str(tmp_path))
+    log = _run("tagdust_hip_rtest", args + [fq, "-o", "gpu"], str(tmp_path))
+    cpu, gpu = _outputs(str(tmp_path), "cpu"), _outputs(str(tmp_path), "gpu")
+    assert cpu and set(cpu) == set(gpu), (sorted(cpu), sorted(gpu), log[-1500:])
+    for k in cpu:
+        assert cpu[k] == gpu[k], "output file *%s differs" % k
+    # the per-artifact hit counts the controller logs (barcode_hmm.c:423-428) come from read_type >> 8
+    def hits(prefix):
+        lines = open(os.path.join(str(tmp_path), prefix + "_logfile.txt")).read().splitlines()
+        return sorted(l.split("\t", 1)[1] for l in lines if "artifact_" in l)   # drop the time stamp
+    assert hits("cpu") == hits("gpu") and hits("cpu")

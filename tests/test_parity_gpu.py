@@ -6,7 +6,7 @@ scores (f, b, r, bar_prob); Q within 1e-4 (BASELINE.json north_star) -- in pract
 import numpy as np
 import pytest
 
-from conftest import load_golden, GOLDEN_NAMES
+from conftest import load_golden, golden_artifacts, GOLDEN_NAMES
 
 pytestmark = pytest.mark.gpu
 
@@ -28,6 +28,11 @@ def ctx(request):
 
 
 def _run(ctx, g, seq=None, offs=None, threshold=None):
+    art = golden_artifacts(g)
+    if art:
+        ctx.set_artifacts(art[0], art[1], art[2], art[3])
+    else:
+        ctx.set_artifacts(None)
     ctx.upload_model(g)
     ctx.set_params(float(g["threshold"]) if threshold is None else threshold, int(g["minlen"]), int(g["dust"]))
     ctx.upload_batch(g["seq"] if seq is None else seq, g["offs"] if offs is None else offs)
@@ -53,7 +58,7 @@ def test_hip_vs_reference_fixture(ctx, name):
     # device-side outcome counters == serial counting (barcode_hmm.c:354-384)
     cnt = ctx.counts()
     for code in range(8):
-        assert cnt[code] == int((g["read_type"] == code).sum())
+        assert cnt[code] == int(((g["read_type"] & 0xFF) == code).sum())   # an artifact hit is (sequence << 8) | 5
     ok = g["read_type"] == 0
     bins = np.bincount((g["barcode"][ok & (g["barcode"] >= 0)] & 0xFF), minlength=256)
     assert np.array_equal(cnt[8:], bins)
