@@ -7,7 +7,8 @@
  *                                              base codes through nuc_code)            -> td_reads_parse
  *   print_all()          src/io.c:757-1016    (file set, ";FP:%d" / ";RQ:%0.2f" header tags, one record per run of
  *                                              kept bases, unextracted reads to "_un")  -> td_writer_*
- * for one input file.
+ * for one input file, and
+ *   get_fasta() / read_fasta()   src/io.c:1826-2001   (-ref artifact sequences)        -> td_fasta_parse
  */
 #ifndef TAGDUST_IO_H
 #define TAGDUST_IO_H
@@ -33,6 +34,16 @@ typedef struct td_reads {
 /* Parse a whole FASTQ/FASTA text held in memory with n_threads host threads (<= 0: pick).  */
 int  td_reads_parse(const char* text, int64_t len, int32_t n_threads, td_reads** out);
 void td_reads_free(td_reads* reads);
+
+/* struct fasta (src/io.h:59-71) as read_fasta() leaves it: ready for td_set_artifacts */
+typedef struct td_fasta {
+	int32_t  n_seq;
+	uint8_t* string;       /* per sequence one 'X' byte, then nuc_code of every alphanumeric character */
+	int32_t* s_index;      /* [n_seq+1]; sequence j = string[s_index[j] .. s_index[j+1]) */
+	char**   names;        /* [n_seq] header line without '>', white space -> '_' */
+} td_fasta;
+int  td_fasta_parse(const char* text, int64_t len, td_fasta** out);
+void td_fasta_free(td_fasta* fasta);
 
 typedef struct td_writer td_writer;
 /* Open print_all()'s file set for one input file: "<prefix>_BC_<barcode>.fq" per barcode + "<prefix>_un.fq", or

@@ -246,3 +246,63 @@ extern "C" int td_writer_close(td_writer* w)
 	delete w;
 	return rc;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// -ref artifact sequences: read_fasta(), src/io.c:1912-2001
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int td_fasta_parse(const char* text, int64_t len, td_fasta** out)
+{
+	if (!text || !out || len < 0) return TD_FAIL;
+	td_fasta* f = (td_fasta*)calloc(1, sizeof(td_fasta));
+	if (!f) return TD_FAIL;
+	// the reference works on a NUL-terminated copy: stop at an embedded NUL like strlen() (:1923)
+	int64_t nbytes = 0;
+	while (nbytes < len && text[nbytes]) nbytes++;
+	int32_t nseq = 0;
+	{   // :1930-1939: a '>' counts once per line, wherever it stands
+		bool stop = false;
+		for (int64_t i = 0; i < nbytes; i++) {
+			const char ch = text[i];
+			if (ch == '>' && !stop) { nseq++; stop = true; }
+			else if (ch == '\n') stop = false;
+		}
+	}
+	f->string = (uint8_t*)malloc((size_t)nbytes + 2);
+	f->s_index = (int32_t*)calloc((size_t)nseq + 1, sizeof(int32_t));
+	f->names = (char**)calloc((size_t)(nseq > 0 ? nseq : 1), sizeof(char*));
+	if (!f->string || !f->s_index || !f->names) { td_fasta_free(f); return TD_FAIL; }
+	auto at = [&](int64_t i) -> char { const char ch = i < nbytes ? text[i] : '\n'; return ch == '\r' ? '\n' : ch; }; // :1937
+	int64_t n = 0;
+	int32_t c = 0;
+	for (int64_t i = 0; i < nbytes; i++) {
+		const char ch = at(i);
+		if (ch == '>') {  // :1954-1984 (every '>' starts a record here; headers that hold a second one are not expected)
+			int64_t j = i + 1;
+			while (at(j) != '\n') j++;
+			if (c >= nseq) break;
+			char* name = (char*)malloc((size_t)(j - i));
+			int32_t l = 0;
+			for (int64_t k = i + 1; k < j; k++) name[l++] = isspace((unsigned char)text[k]) ? '_' : text[k];
+			name[l] = 0;
+			f->names[c] = name;
+			f->s_index[c] = (int32_t)n;
+			f->string[n++] = 'X';
+			i = j;
+			c++;
+		} else if (isalnum((unsigned char)ch)) {
+			f->string[n++] = kCode.t[(unsigned char)ch];
+		}
+	}
+	f->n_seq = c;
+	f->s_index[c] = (int32_t)n;
+	f->string[n] = 'X';
+	*out = f;
+	return TD_OK;
+}
+
+extern "C" void td_fasta_free(td_fasta* f)
+{
+	if (!f) return;
+	if (f->names) for (int32_t j = 0; j < f->n_seq; j++) free(f->names[j]);
+	free(f->names); free(f->string); free(f->s_index); free(f);
+}

@@ -21,7 +21,8 @@ ABI_SYMBOLS = [
     "td_batch_upload", "td_batch_upload_ascii", "td_run", "td_sync", "td_batch_download", "td_counts_reset",
     "td_counts_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_batch_info", "td_set_option", "td_get_option", "td_set_artifacts", "td_spec_source",
 ]
-IO_ABI_SYMBOLS = ["td_reads_parse", "td_reads_free", "td_writer_open", "td_writer_write", "td_writer_close"]
+IO_ABI_SYMBOLS = ["td_reads_parse", "td_reads_free", "td_writer_open", "td_writer_write", "td_writer_close",
+                  "td_fasta_parse", "td_fasta_free"]
 MODEL_ABI_SYMBOLS = ["td_arch_parse", "td_arch_free", "td_sequence_stats", "td_model_build", "td_model_tables_free",
                      "td_calibration_emit", "td_calibration_select", "td_calibration_free", "td_estimate_threshold",
                      "td_compare_architectures"]
@@ -277,6 +278,31 @@ def compare_architectures(ctx, candidates, codes, offs, e=0.05, d=0.1, n_threads
     finally:
         for h in handles:
             lib.td_arch_free(h)
+
+
+class _Fasta(C.Structure):
+    _fields_ = [("n_seq", C.c_int32), ("string", C.POINTER(C.c_uint8)), ("s_index", C.POINTER(C.c_int32)),
+                ("names", C.POINTER(C.c_char_p))]
+
+
+def parse_fasta(text):
+    """-ref artifact sequences as read_fasta() (src/io.c:1912-2001) stores them: (string uint8, s_index int32, names)."""
+    lib = load_library()
+    buf = np.frombuffer(bytes(text), dtype=np.uint8)
+    p = C.POINTER(_Fasta)()
+    lib.td_fasta_parse.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    lib.td_fasta_free.argtypes = [C.c_void_p]
+    if lib.td_fasta_parse(buf.ctypes.data, len(buf), C.byref(p)) != 0:
+        raise TdError("td_fasta_parse failed")
+    try:
+        f = p.contents
+        n = int(f.n_seq)
+        ix = np.ctypeslib.as_array(f.s_index, shape=(n + 1,)).copy()
+        st = np.ctypeslib.as_array(f.string, shape=(max(int(ix[-1]), 1),))[:int(ix[-1])].copy()
+        names = [f.names[j] for j in range(n)]
+    finally:
+        lib.td_fasta_free(p)
+    return st, ix, names
 
 
 class ParsedReads:

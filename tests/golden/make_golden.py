@@ -197,6 +197,9 @@ def synth_reads(path, n, total_len, barcodes, umi_len, spacer, adapter, seed,
 # ---------------------------------------------------------------------------------------------
 # scenarios
 # ---------------------------------------------------------------------------------------------
+EXTRA = {}   # per-scenario input data that is not part of the dump
+
+
 def scenarios(tmp):
     dev = os.path.join(REF, "dev")
     sc = {}
@@ -296,9 +299,12 @@ def scenarios(tmp):
         fa = os.path.join(tmp, "art.fa")
         rng = np.random.RandomState(23)
         arts = ["".join("ACGT"[k] for k in rng.randint(0, 4, L)) for L in (70, 48, 95)]
-        with open(fa, "w") as fh:
+        with open(fa, "w", newline="") as fh:
             for k, a in enumerate(arts):
-                fh.write(">artifact %d\n%s\n" % (k + 1, "\n".join(a[x:x + 40] for x in range(0, len(a), 40))))
+                body = "\n".join(a[x:x + 40] for x in range(0, len(a), 40))
+                if k == 1:
+                    body = body.lower().replace("\n", "\r\n")      # lower case, CRLF line ends
+                fh.write(">artifact %d\n%s\n" % (k + 1, body))
         bars = read_tags(os.path.join(dev, "EDITTAG_4nt_ed_2.txt"), 4)
         comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
         with open(fq, "w") as fh:
@@ -318,6 +324,7 @@ def scenarios(tmp):
                 s_ = b + ins
                 fh.write("@READ%d\n%s\n+\n%s\n" % (i, s_, "I" * len(s_)))
         os.environ["REF_DUMP_THREADS"] = "3"
+        EXTRA["artifacts_b_r"] = {"art_fasta_text": np.frombuffer(open(fa, "rb").read(), np.uint8)}   # input data of -ref
         return fq, ["-seed", "42", "-ref", fa, "-fe", "9", "-1", "B:" + ",".join(bars), "-2", "R:N"]
     sc["artifacts_b_r"] = artifacts
     return sc
@@ -335,6 +342,7 @@ def main():
             log = run(cmd, cwd=tmp)
             os.environ.pop("REF_DUMP_THREADS", None)
             d = parse_dump(dump)
+            d.update(EXTRA.get(name, {}))
             d["cmdline"] = np.array(" ".join(a if not a.startswith(tmp) else os.path.basename(a) for a in args))
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
             kb = os.path.getsize(os.path.join(HERE, name + ".npz")) / 1024

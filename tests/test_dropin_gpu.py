@@ -148,10 +148,7 @@ def test_reference_cli_with_artifact_filter(tmp_path, threads):
     g = load_golden("artifacts_b_r")
     fq, fa = str(tmp_path / "in.fq"), str(tmp_path / "art.fa")
     _write_fastq(g, fq)
-    ix, st = g["art_index"], g["art_string"]
-    with open(fa, "w") as fh:
-        for j in range(int(g["art_n"])):
-            fh.write(">artifact_%d\n%s\n" % (j + 1, "".join("ACGT"[c & 3] for c in st[ix[j] + 1:ix[j + 1]])))
+    open(fa, "wb").write(bytes(g["art_fasta_text"]))
     args = str(g["cmdline"]).split()
     args[args.index("-ref") + 1] = fa
     args += ["-t", str(threads)]

@@ -151,3 +151,18 @@ def test_whole_pipeline_without_the_reference(tmp_path, name):
     assert set(got) == set(want)
     for k in want:
         assert got[k] == want[k], k
+
+
+def test_fasta_parse_matches_reference_read_fasta():
+    """td_fasta_parse against what the reference's get_fasta()/read_fasta() made of the same file (fixture
+    artifacts_b_r: mixed case, CRLF line ends, a blank in the header)."""
+    from tagdust_amd import lib as tdlib
+    g = load_golden("artifacts_b_r")
+    st, ix, names = tdlib.parse_fasta(bytes(g["art_fasta_text"]))
+    assert np.array_equal(ix, g["art_index"])
+    assert np.array_equal(st, g["art_string"])
+    assert names == [b"artifact_1", b"artifact_2", b"artifact_3"]   # white space -> '_' (io.c:1973-1977)
+    st2, ix2, names2 = tdlib.parse_fasta(b"")
+    assert len(ix2) == 1 and ix2[0] == 0 and names2 == []
+    st3, ix3, _ = tdlib.parse_fasta(b">only_a_header\n")
+    assert ix3.tolist() == [0, 1] and st3.tolist() == [ord("X")]
