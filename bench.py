@@ -288,8 +288,9 @@ def main():
                          "algorithmic_bytes_per_read": bpr, "reads_per_launch": n,
                          "traffic_gbps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
                          "traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "note": "algorithmic bytes are tiny (220 B/read); the kernel is VALU/LDS-issue bound and its real HBM "
-                                 "traffic is the backward-row spill (see DESIGN.md)"},
+                         "note": "algorithmic bytes are tiny; the kernel's real HBM traffic is the backward-row spill "
+                                 "(traffic_gbps), which binds it: that access pattern alone reaches 5.5 TB/s "
+                                 "(tools/ubench/spill_stream.hip, DESIGN.md section 4)"},
         }
         out["host_stages"] = {"upload_pack_h2d_ms": t_up * 1e3, "download_d2h_unpack_ms": t_down * 1e3,
                               "note": "td_batch_upload (2-bit packing on host threads + H2D) and td_batch_download (results + rewritten "

@@ -87,6 +87,11 @@ struct td_ctx {
 	std::vector<int64_t> pos_of;     // pos_of[i] = position of read i in the length-sorted device order
 	uint32_t* d_packed = nullptr; size_t cap_packed = 0;
 	int32_t* d_lens = nullptr;    size_t cap_lens = 0;
+	// pinned host staging (H2D of the packed batch, D2H of the outputs): pageable copies run at a fraction of the link
+	// rate and a fresh std::vector per batch is zero-filled first
+	uint32_t* h_packed = nullptr; size_t cap_h_packed = 0;
+	int32_t*  h_lens = nullptr;   size_t cap_h_lens = 0;
+	uint8_t*  h_out = nullptr;    size_t cap_h_out = 0;
 	// -ref artifact filter
 	uint8_t* d_art_text = nullptr; int32_t* d_art_index = nullptr;
 	uint8_t* d_art_left = nullptr; size_t cap_art_left = 0;
@@ -141,6 +146,18 @@ static int ensure(td_ctx* c, T** p, size_t* cap, size_t bytes)
 	if (*p) { HIPCHK(c, hipFree(*p)); *p = nullptr; *cap = 0; }
 	if (bytes == 0) bytes = 256;
 	HIPCHK(c, hipMalloc((void**)p, bytes));
+	*cap = bytes;
+	return TD_OK;
+}
+
+template <typename T>
+static int ensure_pinned(td_ctx* c, T** p, size_t* cap, size_t bytes)
+{
+	if (*cap >= bytes && *p) return TD_OK;
+	if (*p) { HIPCHK(c, hipHostFree(*p)); *p = nullptr; *cap = 0; }
+	if (bytes == 0) bytes = 256;
+	bytes += bytes / 4;   // head room: batches of a run differ a little in size
+	HIPCHK(c, hipHostMalloc((void**)p, bytes, hipHostMallocDefault));
 	*cap = bytes;
 	return TD_OK;
 }
@@ -204,6 +221,8 @@ extern "C" void td_ctx_destroy(td_ctx* c)
 	void* bufs[] = { c->d_hdr, c->d_cols, c->d_hinfo, c->d_pred_off, c->d_pred_idx, c->d_logsum, c->d_counters,
 	                 c->d_packed, c->d_lens, c->d_out, c->d_ws, c->d_art_text, c->d_art_index, c->d_art_left };
 	for (void* p : bufs) if (p) (void)hipFree(p);
+	void* pinned[] = { c->h_packed, c->h_lens, c->h_out };
+	for (void* p : pinned) if (p) (void)hipHostFree(p);
 	if (c->spec_mod) (void)hipModuleUnload(c->spec_mod);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -461,8 +480,13 @@ static int upload_common(td_ctx* c, const uint8_t* codes, const char* ascii, con
 	const int64_t tile_words = (int64_t)(nw2 + nw1) * TD_WAVE;
 
 	// pack: 2 bits per base + 1 bit "is N" per base, lane-interleaved per tile so a wave reads 256 contiguous bytes per word
-	std::vector<uint32_t> packed((size_t)(n_tiles * tile_words), 0u);
-	std::vector<int32_t> lens((size_t)(n_tiles * TD_WAVE), 0);
+	const size_t n_packed = (size_t)(n_tiles * tile_words), n_lens = (size_t)(n_tiles * TD_WAVE);
+	if (ensure_pinned(c, &c->h_packed, &c->cap_h_packed, n_packed * 4) != TD_OK) return TD_FAIL;
+	if (ensure_pinned(c, &c->h_lens, &c->cap_h_lens, n_lens * 4) != TD_OK) return TD_FAIL;
+	uint32_t* const packed = c->h_packed;
+	int32_t* const lens = c->h_lens;
+	parallel_ranges((int64_t)n_packed, [&](int64_t lo, int64_t hi) { memset(packed + lo, 0, (size_t)(hi - lo) * 4); });
+	memset(lens, 0, n_lens * 4);
 	c->codes_host.resize((size_t)offs[n]);
 	// init_nuc_code(), src/nuc_code.c:46-74: ACGTU (either case) -> 0..3(3), everything else 4 (thread-safe static init)
 	struct AscTable {
@@ -492,21 +516,24 @@ static int upload_common(td_ctx* c, const uint8_t* codes, const char* ascii, con
 			const int64_t tile = k / TD_WAVE; const int lane = (int)(k % TD_WAVE);
 			const int l = (int)(offs[i + 1] - offs[i]);
 			lens[(size_t)k] = l;
-			uint32_t* pk = packed.data() + tile * tile_words;
+			uint32_t* pk = packed + tile * tile_words;
+			uint32_t w2 = 0, w1 = 0;   // a word is built in a register and stored once
 			for (int kk = 0; kk < l; kk++) {
 				uint8_t cd = codes ? codes[offs[i] + kk] : asc2code[(uint8_t)ascii[offs[i] + kk]];
 				if (cd > 4) cd = 4;
 				c->codes_host[(size_t)(offs[i] + kk)] = cd;
-				if (cd == 4) pk[(nw2 + (kk >> 5)) * TD_WAVE + lane] |= 1u << (kk & 31);
-				else pk[(kk >> 4) * TD_WAVE + lane] |= (uint32_t)cd << (2 * (kk & 15));
+				if (cd == 4) w1 |= 1u << (kk & 31);
+				else w2 |= (uint32_t)cd << (2 * (kk & 15));
+				if ((kk & 15) == 15 || kk == l - 1) { pk[(kk >> 4) * TD_WAVE + lane] = w2; w2 = 0; }
+				if ((kk & 31) == 31 || kk == l - 1) { pk[(nw2 + (kk >> 5)) * TD_WAVE + lane] = w1; w1 = 0; }
 			}
 		}
 	};
 	parallel_ranges(n, pack_range);
-	if (ensure(c, &c->d_packed, &c->cap_packed, packed.size() * 4) != TD_OK) return TD_FAIL;
-	if (ensure(c, &c->d_lens, &c->cap_lens, lens.size() * 4) != TD_OK) return TD_FAIL;
-	if (!packed.empty()) HIPCHK(c, hipMemcpyAsync(c->d_packed, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, c->stream));
-	if (!lens.empty()) HIPCHK(c, hipMemcpyAsync(c->d_lens, lens.data(), lens.size() * 4, hipMemcpyHostToDevice, c->stream));
+	if (ensure(c, &c->d_packed, &c->cap_packed, n_packed * 4) != TD_OK) return TD_FAIL;
+	if (ensure(c, &c->d_lens, &c->cap_lens, n_lens * 4) != TD_OK) return TD_FAIL;
+	if (n_packed) HIPCHK(c, hipMemcpyAsync(c->d_packed, packed, n_packed * 4, hipMemcpyHostToDevice, c->stream));
+	if (n_lens) HIPCHK(c, hipMemcpyAsync(c->d_lens, lens, n_lens * 4, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 
 	c->n_reads = n; c->n_tiles = (int32_t)n_tiles; c->lmax = lmax; c->nw2 = nw2; c->nw1 = nw1;
@@ -658,55 +685,49 @@ extern "C" int td_batch_download(td_ctx* c, td_read_result* res, int8_t* labels,
 	const int64_t n = c->n_reads;
 	if (n == 0) return TD_OK;
 	const OutLayout ol = out_layout(c->n_tiles, c->lmax, c->nw1);
-	const int64_t np = (int64_t)c->n_tiles * TD_WAVE;
-	if (res) {
-		std::vector<uint8_t> h((size_t)ol.keep);
-		HIPCHK(c, hipMemcpy(h.data(), c->d_out, (size_t)ol.keep, hipMemcpyDeviceToHost));
-		const float* f = (const float*)(h.data() + ol.f); const float* b = (const float*)(h.data() + ol.b);
-		const float* r = (const float*)(h.data() + ol.r); const float* bar = (const float*)(h.data() + ol.bar);
-		const float* q = (const float*)(h.data() + ol.q); const int32_t* ty = (const int32_t*)(h.data() + ol.type);
-		const int32_t* bc = (const int32_t*)(h.data() + ol.barcode); const int32_t* fg = (const int32_t*)(h.data() + ol.finger);
-		parallel_ranges(n, [&](int64_t lo, int64_t hi) {
-			for (int64_t i = lo; i < hi; i++) {
-				const int64_t k = c->pos_of[(size_t)i];
+	// one pinned staging buffer with the device layout; only the regions asked for cross the link
+	if (ensure_pinned(c, &c->h_out, &c->cap_h_out, (size_t)ol.total) != TD_OK) return TD_FAIL;
+	const size_t keep_bytes = (size_t)c->n_tiles * c->nw1 * TD_WAVE * 4;
+	const size_t label_bytes = (size_t)c->n_tiles * (c->lmax + 1) * TD_WAVE;
+	if (res) HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, (size_t)ol.keep, hipMemcpyDeviceToHost, c->stream));
+	if (seq_out) HIPCHK(c, hipMemcpyAsync(c->h_out + ol.keep, c->d_out + ol.keep, keep_bytes, hipMemcpyDeviceToHost, c->stream));
+	if (labels) HIPCHK(c, hipMemcpyAsync(c->h_out + ol.labels, c->d_out + ol.labels, label_bytes, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	const uint8_t* h = c->h_out;
+	const float* f = (const float*)(h + ol.f); const float* b = (const float*)(h + ol.b);
+	const float* r = (const float*)(h + ol.r); const float* bar = (const float*)(h + ol.bar);
+	const float* q = (const float*)(h + ol.q); const int32_t* ty = (const int32_t*)(h + ol.type);
+	const int32_t* bc = (const int32_t*)(h + ol.barcode); const int32_t* fg = (const int32_t*)(h + ol.finger);
+	const int8_t* hl = (const int8_t*)(h + ol.labels);
+	const uint32_t* hk = (const uint32_t*)(h + ol.keep);
+	// un-permute (device order is length-sorted) and un-interleave ([..][64 lanes] -> per read), all three in one pass
+	parallel_ranges(n, [&](int64_t lo, int64_t hi) {
+		for (int64_t i = lo; i < hi; i++) {
+			const int64_t k = c->pos_of[(size_t)i];
+			const int64_t tile = k / TD_WAVE; const int lane = (int)(k % TD_WAVE);
+			const int l = (int)(c->offs[i + 1] - c->offs[i]);
+			if (res) {
 				res[i].f_score = f[k]; res[i].b_score = b[k]; res[i].r_score = r[k]; res[i].bar_prob = bar[k];
 				res[i].mapq = q[k]; res[i].read_type = ty[k]; res[i].barcode = bc[k]; res[i].fingerprint = fg[k];
 			}
-		});
-		(void)np;
-	}
-	if (labels) {
-		const size_t bytes = (size_t)c->n_tiles * (c->lmax + 1) * TD_WAVE;
-		std::vector<int8_t> h(bytes);
-		HIPCHK(c, hipMemcpy(h.data(), c->d_out + ol.labels, bytes, hipMemcpyDeviceToHost));
-		parallel_ranges(n, [&](int64_t lo, int64_t hi) {
-			for (int64_t i = lo; i < hi; i++) {
-				const int64_t k = c->pos_of[(size_t)i];
-				const int64_t tile = k / TD_WAVE; const int lane = (int)(k % TD_WAVE);
-				const int l = (int)(c->offs[i + 1] - c->offs[i]);
-				const int8_t* src = h.data() + tile * (int64_t)(c->lmax + 1) * TD_WAVE;
+			if (labels) {
+				const int8_t* src = hl + tile * (int64_t)(c->lmax + 1) * TD_WAVE + lane;
 				int8_t* dst = labels + c->offs[i] + i;
-				for (int kk = 0; kk <= l; kk++) dst[kk] = src[kk * TD_WAVE + lane];
+				for (int kk = 0; kk <= l; kk++) dst[kk] = src[kk * TD_WAVE];
 			}
-		});
-	}
-	if (seq_out) {
-		const size_t words = (size_t)c->n_tiles * c->nw1 * TD_WAVE;
-		std::vector<uint32_t> h(words);
-		HIPCHK(c, hipMemcpy(h.data(), c->d_out + ol.keep, words * 4, hipMemcpyDeviceToHost));
-		parallel_ranges(n, [&](int64_t lo, int64_t hi) {
-			for (int64_t i = lo; i < hi; i++) {
-				const int64_t k = c->pos_of[(size_t)i];
-				const int64_t tile = k / TD_WAVE; const int lane = (int)(k % TD_WAVE);
-				const int l = (int)(c->offs[i + 1] - c->offs[i]);
-				const uint32_t* kw = h.data() + tile * (int64_t)c->nw1 * TD_WAVE;
-				for (int kk = 0; kk < l; kk++) {
-					const bool keep = (kw[(kk >> 5) * TD_WAVE + lane] >> (kk & 31)) & 1u;
-					seq_out[c->offs[i] + kk] = keep ? c->codes_host[(size_t)(c->offs[i] + kk)] : 65; // spacer byte, barcode_hmm.c:3348
+			if (seq_out) {
+				const uint32_t* kw = hk + tile * (int64_t)c->nw1 * TD_WAVE + lane;
+				const uint8_t* cd = c->codes_host.data() + c->offs[i];
+				uint8_t* dst = seq_out + c->offs[i];
+				for (int k0 = 0; k0 < l; k0 += 32) {
+					const uint32_t w = kw[(k0 >> 5) * TD_WAVE];
+					const int e = l - k0 < 32 ? l - k0 : 32;
+					if (w == 0xFFFFFFFFu) memcpy(dst + k0, cd + k0, (size_t)e);      // whole word kept (unextracted reads)
+					else for (int kk = 0; kk < e; kk++) dst[k0 + kk] = ((w >> kk) & 1u) ? cd[k0 + kk] : 65; // spacer byte, barcode_hmm.c:3348
 				}
 			}
-		});
-	}
+		}
+	});
 	return TD_OK;
 }
 
