@@ -339,3 +339,67 @@ def test_long_reads_switch_to_clamped_logsum(monkeypatch):
         assert np.array_equal(_bits(res0[k]), _bits(res1[k]))
     assert np.array_equal(labels0, labels1) and np.array_equal(labels0, g["labels"])
     assert np.array_equal(seq0, seq1) and np.array_equal(seq0, g["seq_after"])
+
+
+def test_full_size_batch_properties():
+    """BASELINE.json's bench shape at full batch size (2^20 reads of 150 bp, config-3 architecture): the oracle cannot
+    cover a million reads in seconds, so the batch is checked through properties that do not depend on its size --
+    a batch decodes like its permutation, like its halves, and like itself a second time; the device counters add up;
+    and a random sample is bit-identical to the oracle."""
+    import bench
+    from oracle import pyoracle
+    from tagdust_amd import TagdustHip
+    model = bench.load_model()
+    n, L = 1 << 20, bench.READ_LEN
+    reads = bench.synth_batch(n, 20240607).reshape(n, L)
+    offs = np.arange(n + 1, dtype=np.int64) * L
+    c = TagdustHip(0)
+    try:
+        c.set_option("specialize", 1)
+        c.upload_model(model)
+        c.set_params(float(model["threshold"]), int(model["minlen"]), int(model["dust"]))
+
+        def decode(r):
+            c.upload_batch(r.reshape(-1), np.arange(len(r) + 1, dtype=np.int64) * L)
+            c.counts_reset()
+            c.run()
+            return c.download() + (c.counts(),)
+
+        res, labels, seq, cnt = decode(reads)
+        # counters == serial counting over the results
+        assert int(cnt[:8].sum()) == n
+        for code in range(8):
+            assert cnt[code] == int(((res["read_type"] & 0xFF) == code).sum())
+        ok = (res["read_type"] == 0) & (res["barcode"] >= 0)
+        assert np.array_equal(cnt[8:], np.bincount(res["barcode"][ok] & 0xFF, minlength=256))
+        assert 0.80 * n < cnt[0] < 0.95 * n                                 # ~90 % of the synthetic reads carry the architecture
+        # idempotence
+        res2, labels2, seq2, _ = decode(reads)
+        assert res.tobytes() == res2.tobytes() and np.array_equal(labels, labels2) and np.array_equal(seq, seq2)
+        # permutation: the device order is length-sorted and tiles hold 64 neighbours; a read must not care who they are
+        perm = np.random.default_rng(5).permutation(n)
+        resp, labelsp, seqp, cntp = decode(reads[perm])
+        assert resp.tobytes() == res[perm].tobytes()
+        assert np.array_equal(labelsp.reshape(n, L + 1), labels.reshape(n, L + 1)[perm])
+        assert np.array_equal(seqp.reshape(n, L), seq.reshape(n, L)[perm])
+        assert np.array_equal(cntp, cnt)
+        # halves
+        h = n // 2
+        ra, la, sa, ca = decode(reads[:h])
+        rb, lb, sb, cb = decode(reads[h:])
+        assert ra.tobytes() + rb.tobytes() == res.tobytes()
+        assert np.array_equal(np.concatenate([la, lb]), labels) and np.array_equal(np.concatenate([sa, sb]), seq)
+        assert np.array_equal(ca + cb, cnt)
+    finally:
+        c.close()
+    # a random sample against the oracle, bit for bit
+    pick = np.sort(np.random.default_rng(6).choice(n, 3000, replace=False))
+    om = pyoracle.OracleModel(model)
+    ores, olab, oseq = pyoracle.label_batch(om, reads[pick].reshape(-1), offs[:len(pick) + 1], float(model["threshold"]),
+                                            int(model["minlen"]), int(model["dust"]), n_threads=8)
+    for k, ok_ in (("b_score", "b_score"), ("f_score", "f_score"), ("r_score", "r_score"), ("bar_prob", "bar_prob"), ("mapq", "Q")):
+        assert np.array_equal(_bits(res[k][pick]), _bits(ores[ok_]))
+    for k in ("read_type", "barcode", "fingerprint"):
+        assert np.array_equal(res[k][pick], ores[k])
+    assert np.array_equal(labels.reshape(n, L + 1)[pick].reshape(-1), olab)
+    assert np.array_equal(seq.reshape(n, L)[pick].reshape(-1), oseq)
