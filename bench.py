@@ -140,8 +140,48 @@ def cpu_baseline(model, n_sample, seed):
     t0 = time.perf_counter()
     pyoracle.label_batch(om, reads.reshape(-1), offs, float(model["threshold"]), 16, 100, cores)
     dt = time.perf_counter() - t0
-    return {"value": n_sample / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "%d reads of the same synthetic workload, oracle/td_oracle.c with %d pthreads, %.1f s wall" % (n_sample, cores, dt)}
+    out = {"value": n_sample / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+           "sample": "%d reads of the same synthetic workload, oracle/td_oracle.c with %d pthreads, %.1f s wall" % (n_sample, cores, dt)}
+    ref = reference_cli_baseline(reads[:min(n_sample, 20000)], cores)
+    if ref:
+        out["reference_binary"] = ref
+    return out
+
+
+def reference_cli_baseline(reads, cores):
+    """The reference itself (oracle/_ref/tagdust, built by `make -C oracle ref` in the build container and carried to
+    the GPU box with the snapshot), whole job on a bounded sample: FASTQ in, -t <cores>, demultiplexed FASTQ out.
+    -Q skips the threshold calibration prologue.  Reported beside the port; None when the binary is
+    absent or the workload is not config 3."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(REPO, "oracle", "_ref", "tagdust")
+    if not os.path.exists(exe) or _ACTIVE["fixture"] != "c3_b6_s_r_p":
+        return None
+    n, L = reads.shape
+    with tempfile.TemporaryDirectory() as tmp:
+        rec = np.empty((n, 2 * L + 16), np.uint8)          # "@r0000000\n" + seq + "\n+\n" + qual + "\n"
+        names = np.char.zfill(np.arange(n).astype("U7"), 7)
+        head = np.frombuffer(("".join("@r%s\n" % x for x in names)).encode(), np.uint8).reshape(n, 10)
+        rec[:, :10] = head
+        rec[:, 10:10 + L] = np.frombuffer(b"ACGTN", np.uint8)[reads]
+        rec[:, 10 + L:13 + L] = np.frombuffer(b"\n+\n", np.uint8)
+        rec[:, 13 + L:13 + 2 * L] = ord("I")
+        rec[:, 13 + 2 * L] = ord("\n")
+        fq = os.path.join(tmp, "in.fq")
+        rec[:, :14 + 2 * L].tofile(fq)
+        cmd = [exe, "-t", str(cores), "-Q", "20", "-1", "B:" + ",".join(BARCODES), "-2", "S:" + SPACER, "-3", "R:N",
+               "-4", "P:" + ADAPTER, fq, "-o", os.path.join(tmp, "out")]
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        except Exception:
+            return None
+        dt = time.perf_counter() - t0
+        if p.returncode != 0:
+            return None
+    return {"value": n / dt, "unit": "reads/s", "cores": cores, "kind": "reference",
+            "sample": "%d reads, oracle/_ref/tagdust -t %d -Q 20 (no calibration), FASTQ in and out, %.1f s wall" % (n, cores, dt)}
 
 
 def main():
