@@ -449,10 +449,60 @@ extern "C" void td_model_tables_free(td_model_tables* t)
 // ---------------------------------------------------------------------------------------------------------
 namespace {
 
+// glibc's rand() is random_r() of type TYPE_3: an additive feedback generator x[i] = x[i-3] + x[i-31] (mod 2^32) over a
+// 31-word state seeded by the Lehmer recurrence 16807 * x mod (2^31 - 1), first 310 outputs discarded, result = x >> 1.
+// The calibration draws ~10^8 numbers one at a time; an inline copy of that recurrence avoids the locked library call
+// for each.  It is only used after its first outputs have been checked against this process's own srand()/rand(); any
+// other C library keeps calling rand().
+struct GlibcRand {
+	int32_t r[34];
+	int f = 3, b = 0;   // front / rear indices into the 31-word ring
+	void seed(uint32_t s)
+	{
+		if (s == 0) s = 1;
+		r[0] = (int32_t)s;
+		for (int i = 1; i < 31; i++) {
+			const long hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+			long word = 16807 * lo - 2836 * hi;
+			if (word < 0) word += 2147483647;
+			r[i] = (int32_t)word;
+		}
+		f = 3; b = 0;
+		for (int i = 0; i < 310; i++) (void)next();
+	}
+	int next()
+	{
+		const uint32_t v = (uint32_t)r[f] + (uint32_t)r[b];
+		r[f] = (int32_t)v;
+		if (++f >= 31) f = 0;
+		if (++b >= 31) b = 0;
+		return (int)(v >> 1);
+	}
+	static bool matches_libc()
+	{
+		static const bool ok = [] {
+			for (uint32_t s : { 1u, 42u, 2654435761u }) {
+				GlibcRand g; g.seed(s);
+				srand(s);
+				for (int i = 0; i < 1000; i++) if (g.next() != rand()) return false;
+			}
+			return RAND_MAX == 2147483647;
+		}();
+		return ok;
+	}
+};
+
 struct Rng {
 	int kind;            // 0 = libc rand(), 1 = the reference's RTEST LCG (misc.c:878-887)
 	uint32_t next = 1;
-	void seed(uint32_t s) { if (kind) next = s; else srand(s); }
+	bool own = false;
+	GlibcRand g;
+	void seed(uint32_t s)
+	{
+		if (kind) { next = s; return; }
+		own = GlibcRand::matches_libc();
+		if (own) g.seed(s); else srand(s);
+	}
 	// "(float)rand()/(float)my_rand_max", barcode_hmm.c:2610,2721 (my_rand_max = RAND_MAX, or 32768 under RTEST)
 	double draw()
 	{
@@ -460,7 +510,7 @@ struct Rng {
 			next = next * 1103515245u + 12345u;
 			return (float)(int)((unsigned)(next / 65536) % 32768) / (float)32768u;
 		}
-		return (float)rand() / (float)(unsigned)RAND_MAX;
+		return (float)(own ? g.next() : rand()) / (float)(unsigned)RAND_MAX;
 	}
 };
 
@@ -475,68 +525,102 @@ struct ModelView { // flattened tables with the per-segment offsets the emitters
 	int col(int seg, int hmm, int g) const { return col_off[(size_t)seg] + hmm * m->n_col[seg] + g; }
 };
 
+// The emitters compare one uniform draw against a running sum of probabilities that restarts from log 0 at every step
+// and folds the same model parameters in the same order (logsum in float, scaledprob2prob through exp in double).
+// Those thresholds depend on the model only, so they are evaluated once -- with exactly those operations -- and a step
+// becomes a search for the first threshold above the draw: identical decisions, no exp per comparison.
+struct EmitTables {
+	std::vector<std::vector<double>> silent;   // per segment: thresholds after (hmm i, column j, M) and (i, j, I), in loop order
+	std::vector<double> tM, tI, tD;            // per column: 3 (MM, MI, MD), 2 (II, IM), 1 (DD)
+	std::vector<double> eM, eI;                // per column: 5 emission thresholds each
+	double bg[5];
+	EmitTables(const ModelView& v)
+	{
+		const td_model_desc* m = v.m;
+		silent.resize((size_t)m->S);
+		for (int seg = 0; seg < m->S; seg++) {
+			double sum = p2sp(0.0f);
+			for (int i = 0; i < m->n_hmm[seg]; i++)
+				for (int j = 0; j < m->n_col[seg]; j++) {
+					sum = logsum_f(sum, m->sM[v.col(seg, i, j)]); silent[(size_t)seg].push_back(sp2p(sum));
+					sum = logsum_f(sum, m->sI[v.col(seg, i, j)]); silent[(size_t)seg].push_back(sp2p(sum));
+				}
+		}
+		const size_t C = (size_t)m->C;
+		tM.resize(C * 3); tI.resize(C * 2); tD.resize(C); eM.resize(C * 5); eI.resize(C * 5);
+		for (size_t c = 0; c < C; c++) {
+			const float* t = m->trans + c * 9;
+			double sum = p2sp(0.0f);
+			sum = logsum_f(sum, t[MM]); tM[c * 3 + 0] = sp2p(sum);
+			sum = logsum_f(sum, t[MI]); tM[c * 3 + 1] = sp2p(sum);
+			sum = logsum_f(sum, t[MD]); tM[c * 3 + 2] = sp2p(sum);
+			sum = p2sp(0.0f);
+			sum = logsum_f(sum, t[II]); tI[c * 2 + 0] = sp2p(sum);
+			sum = logsum_f(sum, t[IM]); tI[c * 2 + 1] = sp2p(sum);
+			sum = p2sp(0.0f);
+			sum = logsum_f(sum, t[DD]); tD[c] = sp2p(sum);
+			sum = p2sp(0.0f);
+			for (int nuc = 0; nuc < 5; nuc++) { sum = logsum_f(sum, m->eM[c * 5 + (size_t)nuc]); eM[c * 5 + (size_t)nuc] = sp2p(sum); }
+			sum = p2sp(0.0f);
+			for (int nuc = 0; nuc < 5; nuc++) { sum = logsum_f(sum, m->eI[c * 5 + (size_t)nuc]); eI[c * 5 + (size_t)nuc] = sp2p(sum); }
+		}
+		double sum = p2sp(0.0f);
+		for (int nuc = 0; nuc < 5; nuc++) { sum = logsum_f(sum, m->bg[nuc]); bg[nuc] = sp2p(sum); }
+	}
+};
+
 // emit_read_sequence(), barcode_hmm.c:2696-3046
-void emit_read(const ModelView& v, Rng& rng, int average_length, std::vector<uint8_t>& seq)
+void emit_read(const ModelView& v, const EmitTables& T, Rng& rng, int average_length, std::vector<uint8_t>& seq)
 {
 	const td_model_desc* m = v.m;
 	double r = rng.draw();
-	double sum;
 	size_t current_length = 0;
 	seq.clear();
 	while ((int)current_length < average_length) {
 		int state = 0, column = 0, hmm = 0, segment = 0; // 0 silent, 1 M, 2 I, 3 D
 		while (1) {
 			r = rng.draw();
-			sum = p2sp(0.0f);
 			switch (state) {
 			case 0: {
-				const int len = m->n_col[segment];
-				bool done = false;
-				for (int i = 0; i < m->n_hmm[segment] && !done; i++) {
-					for (int j = 0; j < len; j++) {
-						sum = logsum_f(sum, m->sM[v.col(segment, i, j)]);
-						if (r < sp2p(sum)) { state = 1; column = j; hmm = i; done = true; break; }
-						sum = logsum_f(sum, m->sI[v.col(segment, i, j)]);
-						if (r < sp2p(sum)) { state = 2; column = j; hmm = i; done = true; break; }
-					}
+				// first (hmm, column, M|I) whose running sum exceeds the draw; the sums never decrease, so the first
+				// threshold above r is found by bisection.  No hit leaves the state silent (and draws again), as in the
+				// reference's loop.
+				const std::vector<double>& th = T.silent[(size_t)segment];
+				const size_t k = (size_t)(std::upper_bound(th.begin(), th.end(), r) - th.begin());
+				if (k < th.size()) {
+					const int len = m->n_col[segment];
+					state = (k & 1) ? 2 : 1;
+					hmm = (int)(k / 2) / len;
+					column = (int)(k / 2) % len;
 				}
 				break;
 			}
 			case 1: {
-				const float* t = m->trans + (size_t)v.col(segment, hmm, column) * 9;
-				sum = logsum_f(sum, t[MM]);
-				if (r < sp2p(sum)) { state = 1; column++; break; }
-				sum = logsum_f(sum, t[MI]);
-				if (r < sp2p(sum)) { state = 2; break; }
-				sum = logsum_f(sum, t[MD]);
-				if (r < sp2p(sum)) { state = 3; column++; break; }
+				const double* t = &T.tM[(size_t)v.col(segment, hmm, column) * 3];
+				if (r < t[0]) { state = 1; column++; break; }
+				if (r < t[1]) { state = 2; break; }
+				if (r < t[2]) { state = 3; column++; break; }
 				state = 0; segment++; column = 0; hmm = 0; // MSKIP takes whatever is left
 				break;
 			}
 			case 2: {
-				const float* t = m->trans + (size_t)v.col(segment, hmm, column) * 9;
-				sum = logsum_f(sum, t[II]);
-				if (r < sp2p(sum)) { state = 2; break; }
-				sum = logsum_f(sum, t[IM]);
-				if (r < sp2p(sum)) { state = 1; column++; break; }
+				const double* t = &T.tI[(size_t)v.col(segment, hmm, column) * 2];
+				if (r < t[0]) { state = 2; break; }
+				if (r < t[1]) { state = 1; column++; break; }
 				state = 0; segment++; column = 0; hmm = 0; // ISKIP
 				break;
 			}
 			case 3: {
-				const float* t = m->trans + (size_t)v.col(segment, hmm, column) * 9;
-				sum = logsum_f(sum, t[DD]);
-				if (r < sp2p(sum)) { state = 3; column++; break; }
+				if (r < T.tD[(size_t)v.col(segment, hmm, column)]) { state = 3; column++; break; }
 				state = 1; column++; // DM
 				break;
 			}
 			}
 			r = rng.draw();
-			sum = p2sp(0.0f);
 			if (state == 1 || state == 2) {
-				const float* e = (state == 1 ? m->eM : m->eI) + (size_t)v.col(segment, hmm, column) * 5;
+				const double* e = &(state == 1 ? T.eM : T.eI)[(size_t)v.col(segment, hmm, column) * 5];
 				for (int nuc = 0; nuc < 5; nuc++) {
-					sum = logsum_f(sum, e[nuc]);
-					if (r < sp2p(sum)) {
+					if (r < e[nuc]) {
 						if (seq.size() <= current_length) seq.resize(current_length + 1);
 						seq[current_length++] = (uint8_t)nuc;
 						break;
@@ -551,18 +635,15 @@ void emit_read(const ModelView& v, Rng& rng, int average_length, std::vector<uin
 }
 
 // emit_random_sequence(), barcode_hmm.c:2599-2680
-void emit_random(const td_model_desc* m, Rng& rng, int average_length, std::vector<uint8_t>& seq)
+void emit_random(const EmitTables& T, Rng& rng, int average_length, std::vector<uint8_t>& seq)
 {
 	size_t current_length = 0;
 	double r = rng.draw();
-	double sum;
 	seq.clear();
 	while ((int)current_length < average_length) {
 		while (1) {
-			sum = p2sp(0.0f);
 			for (int nuc = 0; nuc < 5; nuc++) {
-				sum = logsum_f(sum, m->bg[nuc]);
-				if (r < sp2p(sum)) {
+				if (r < T.bg[nuc]) {
 					if (seq.size() <= current_length) seq.resize(current_length + 1);
 					seq[current_length++] = (uint8_t)nuc;
 					break;
@@ -605,16 +686,17 @@ extern "C" int td_calibration_emit(const td_arch* a, const td_seq_stats* ssi, fl
 	std::vector<int64_t> offs(1, 0);
 	std::vector<uint8_t> rnd;
 	const ModelView view(&em->desc);
+	const EmitTables tables(view);
 	const int avg = (int)ssi->average_length;
 	int readnum = 0;
 	for (int i = 0; i < binsize * 2; i++) {             // :88-100
-		emit_read(view, rng, avg, one);
+		emit_read(view, tables, rng, avg, one);
 		all.insert(all.end(), one.begin(), one.end());
 		offs.push_back((int64_t)all.size()); rnd.push_back(0);
 		readnum++;
 	}
 	for (int i = 0; i < binsize + binsize; i++) {       // :102-113
-		emit_random(&em->desc, rng, avg, one);
+		emit_random(tables, rng, avg, one);
 		all.insert(all.end(), one.begin(), one.end());
 		offs.push_back((int64_t)all.size()); rnd.push_back(1);
 		readnum++;
