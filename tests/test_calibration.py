@@ -90,3 +90,38 @@ def test_compare_architectures_on_gpu():
         z = np.float32(lsum(float(z), float(x)))
     want = np.array([np.float32(np.exp(np.float64(np.float32(x - z)))) if np.isfinite(x - z) else np.float32(0) for x in norm], np.float32)
     assert np.array_equal(post.view(np.uint32), want.view(np.uint32)), (post, want)
+
+
+def test_libc_rng_variant_matches_the_reference_binary(tmp_path):
+    """The production path (C library rand(), 400 000 simulated reads): the threshold td_calibration_emit + scoring +
+    td_calibration_select give must be the one the reference's regular (non -DRTEST) binary logs for the same input
+    and -seed.  Needs oracle/_ref/tagdust (built in the build container by `make -C oracle ref`); the emitted reads are
+    scored by the CPU oracle here, by the device in td_estimate_threshold."""
+    import os
+    import re
+    import subprocess
+    from conftest import REPO
+    from oracle import pyoracle
+    exe = os.path.join(REPO, "oracle", "_ref", "tagdust")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/tagdust not built")
+    g = load_golden("c2_b4_r")
+    fq = str(tmp_path / "in.fq")
+    names = bytes(g["names"]).split(b"\n")
+    offs = g["offs"]
+    with open(fq, "wb") as fh:
+        for i in range(int(g["n_reads"])):
+            s = bytes(np.frombuffer(b"ACGTN", np.uint8)[g["seq"][offs[i]:offs[i + 1]]])
+            fh.write(b"@" + names[i] + b"\n" + s + b"\n+\n" + bytes(g["qual"][offs[i]:offs[i + 1]]) + b"\n")
+    p = subprocess.run([exe, "-t", "8"] + str(g["cmdline"]).split() + [fq, "-o", str(tmp_path / "out")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-1500:]
+    m = re.search(r"Selected Threshold::? ([0-9.eE+-]+)", p.stdout.decode(errors="replace"))
+    assert m, p.stdout.decode(errors="replace")[-1500:]
+    want = float(m.group(1))
+    segs = _segments(g)
+    codes, offs2, is_random = tdlib.calibration_emit(segs, g["seq"], g["offs"], float(g["d"]), seed=42, n_reads=400000, rng=0)
+    scoring, _ = tdlib.build_model(segs, g["seq"], g["offs"], 0.05, float(g["d"]))
+    res, _, _ = pyoracle.label_batch(pyoracle.OracleModel(scoring), codes, offs2, 0.0, int(g["minlen"]), 0, 8)
+    thr = tdlib.calibration_select(res["Q"], is_random)
+    assert abs(thr - want) < 5e-7 * max(1.0, abs(want)), (thr, want)       # the log prints %f (six decimals)
