@@ -10,9 +10,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/tagdust_model.h"
+#include "td_jit.h"
 
 namespace {
 
@@ -748,8 +751,21 @@ extern "C" int td_estimate_threshold(td_ctx* ctx, const td_arch* a, const td_seq
                                      int32_t n_reads, int32_t rng, float* threshold)
 {
 	if (!ctx || !threshold) return TD_FAIL;
+	// The scoring model's kernel is compiled (seconds) while the host emits the reads (seconds, bound to one thread by the
+	// rand() sequence): the compile only fills the code cache td_model_upload looks into.
+	std::thread warm;
+	td_model_tables* scoring = nullptr;
+	int32_t specialize = 0;
+	const bool overlap = getenv("TD_CAL_OVERLAP") ? atoi(getenv("TD_CAL_OVERLAP")) != 0 : true;
+	if (overlap && td_get_option(ctx, "specialize", &specialize) == TD_OK && specialize &&
+	    td_model_build(a, ssi, 0.05f, d, &scoring) == TD_OK) {
+		warm = std::thread([scoring] { std::vector<char> code; std::string log; (void)td_spec_compile(&scoring->desc, code, log); });
+	}
 	td_calibration* cal = nullptr;
-	if (td_calibration_emit(a, ssi, d, seed, n_reads, rng, &cal) != TD_OK) return TD_FAIL;
+	const int emitted = td_calibration_emit(a, ssi, d, seed, n_reads, rng, &cal);
+	if (warm.joinable()) warm.join();
+	td_model_tables_free(scoring);
+	if (emitted != TD_OK) return TD_FAIL;
 	int rc = TD_FAIL;
 	std::vector<td_read_result> res((size_t)cal->n_reads);
 	if (td_model_upload(ctx, &cal->scoring->desc) == TD_OK && td_batch_upload(ctx, cal->codes, cal->offs, cal->n_reads) == TD_OK &&
