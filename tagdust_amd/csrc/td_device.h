@@ -112,7 +112,7 @@ struct TdSpecLayout {
 	int64_t dp;      // f32   [lmax][H][64]
 	int64_t path;    // u32   [lmax][ceil(H/4)][64]   four path bytes per word
 	int64_t total;   // f32   [H][64]
-	int64_t dust;    // u8    [64][64]
+	int64_t dust;    // (unused)
 	int64_t acc;     // f32   [H][64]   label-DP row when H is too large for registers
 };
 

@@ -6,10 +6,12 @@
 // (double) log(); sequencer_error_rate / indel_frequency are floats (src/interface.h:119-120) that become doubles only
 // when passed to set_hmm_transition_parameters().
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -507,13 +509,17 @@ struct Rng {
 		if (own) g.seed(s); else srand(s);
 	}
 	// "(float)rand()/(float)my_rand_max", barcode_hmm.c:2610,2721 (my_rand_max = RAND_MAX, or 32768 under RTEST)
+	long long n_draws = 0;
 	double draw()
 	{
+		n_draws++;
 		if (kind) {
 			next = next * 1103515245u + 12345u;
-			return (float)(int)((unsigned)(next / 65536) % 32768) / (float)32768u;
+			return (float)(int)((unsigned)(next / 65536) % 32768) * 0x1p-15f;   // / 32768.0f, exactly
 		}
-		return (float)(own ? g.next() : rand()) / (float)(unsigned)RAND_MAX;
+		// (float)RAND_MAX is 2^31 for glibc's 2^31 - 1, so the division is an exact scaling
+		if (own) return (float)g.next() * 0x1p-31f;
+		return (float)rand() / (float)(unsigned)RAND_MAX;
 	}
 };
 
@@ -622,12 +628,11 @@ void emit_read(const ModelView& v, const EmitTables& T, Rng& rng, int average_le
 			r = rng.draw();
 			if (state == 1 || state == 2) {
 				const double* e = &(state == 1 ? T.eM : T.eI)[(size_t)v.col(segment, hmm, column) * 5];
-				for (int nuc = 0; nuc < 5; nuc++) {
-					if (r < e[nuc]) {
-						if (seq.size() <= current_length) seq.resize(current_length + 1);
-						seq[current_length++] = (uint8_t)nuc;
-						break;
-					}
+				// first threshold above the draw, without a data-dependent branch per candidate (the thresholds ascend)
+				const int nuc = (int)!(r < e[0]) + (int)!(r < e[1]) + (int)!(r < e[2]) + (int)!(r < e[3]) + (int)!(r < e[4]);
+				if (nuc < 5) {
+					if (seq.size() <= current_length) seq.resize(2 * current_length + 64);
+					seq[current_length++] = (uint8_t)nuc;
 				}
 			}
 			if (segment == m->S) break;
@@ -643,17 +648,16 @@ void emit_random(const EmitTables& T, Rng& rng, int average_length, std::vector<
 	size_t current_length = 0;
 	double r = rng.draw();
 	seq.clear();
+	const double stop = 1.0 - (1.0 / (float)average_length);
 	while ((int)current_length < average_length) {
 		while (1) {
-			for (int nuc = 0; nuc < 5; nuc++) {
-				if (r < T.bg[nuc]) {
-					if (seq.size() <= current_length) seq.resize(current_length + 1);
-					seq[current_length++] = (uint8_t)nuc;
-					break;
-				}
+			const int nuc = (int)!(r < T.bg[0]) + (int)!(r < T.bg[1]) + (int)!(r < T.bg[2]) + (int)!(r < T.bg[3]) + (int)!(r < T.bg[4]);
+			if (nuc < 5) {
+				if (seq.size() <= current_length) seq.resize(2 * current_length + 64);
+				seq[current_length++] = (uint8_t)nuc;
 			}
 			r = rng.draw();
-			if (r > 1.0 - (1.0 / (float)average_length)) break;
+			if (r > stop) break;
 		}
 		if ((int)current_length < average_length) current_length = 0;
 	}
@@ -692,12 +696,15 @@ extern "C" int td_calibration_emit(const td_arch* a, const td_seq_stats* ssi, fl
 	const EmitTables tables(view);
 	const int avg = (int)ssi->average_length;
 	int readnum = 0;
+	const auto tc0 = std::chrono::steady_clock::now();
 	for (int i = 0; i < binsize * 2; i++) {             // :88-100
 		emit_read(view, tables, rng, avg, one);
 		all.insert(all.end(), one.begin(), one.end());
 		offs.push_back((int64_t)all.size()); rnd.push_back(0);
 		readnum++;
 	}
+	const auto tc1 = std::chrono::steady_clock::now();
+	const long long d1 = rng.n_draws;
 	for (int i = 0; i < binsize + binsize; i++) {       // :102-113
 		emit_random(tables, rng, avg, one);
 		all.insert(all.end(), one.begin(), one.end());
@@ -707,6 +714,12 @@ extern "C" int td_calibration_emit(const td_arch* a, const td_seq_stats* ssi, fl
 	}
 	td_model_tables_free(em);
 	if (td_model_build(a, ssi, 0.05f, d, &cal->scoring) != TD_OK) { free(cal); return TD_FAIL; } // :117-119
+	if (getenv("TD_CAL_DEBUG")) {
+		const auto tc2 = std::chrono::steady_clock::now();
+		fprintf(stderr, "calibration: model reads %.2f s (%lld draws), random reads %.2f s (%lld draws), %d reads\n",
+		        std::chrono::duration<double>(tc1 - tc0).count(), d1, std::chrono::duration<double>(tc2 - tc1).count(),
+		        rng.n_draws - d1, readnum);
+	}
 	cal->n_reads = readnum;
 	cal->codes = (uint8_t*)malloc(all.size() + 1);
 	cal->offs = (int64_t*)malloc(sizeof(int64_t) * offs.size());
