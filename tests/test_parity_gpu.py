@@ -426,3 +426,93 @@ def test_disk_cache_of_compiled_kernels(tmp_path, monkeypatch):
     # so check the loader by reading the file back and comparing with what a fresh compile would produce
     blob = open(os.path.join(tmp_path, files[0]), "rb").read()
     assert blob[:4] == b"\x7fELF" and len(blob) > 10000
+
+
+def _random_arch(rng):
+    """A random read architecture in the reference's -1 .. -k segment syntax, with reads that (mostly) follow it."""
+    def dna(n):
+        return "".join("ACGT"[x] for x in rng.randint(0, 4, n))
+    segs, parts = [], []            # parts: callables producing the segment's text for one read
+    if rng.random_sample() < 0.3:
+        segs.append("O:N"); parts.append(lambda: dna(rng.randint(0, 4)))
+    if rng.random_sample() < 0.4:
+        p5 = dna(rng.randint(4, 16)); segs.append("P:" + p5); parts.append(lambda p5=p5: p5[rng.randint(0, len(p5)):])
+    nb = int(rng.choice([0, 2, 5, 9, 20, 30]))          # 20 / 30: run-time HMM loop and the H > 32 label path
+    if nb:
+        L = int(rng.randint(4, 8))
+        bars = sorted({dna(L) for _ in range(nb)})
+        segs.append("B:" + ",".join(bars)); parts.append(lambda bars=bars: bars[rng.randint(len(bars))])
+    if rng.random_sample() < 0.4:
+        nf = int(rng.randint(4, 9)); segs.append("F:" + "N" * nf); parts.append(lambda nf=nf: dna(nf))
+    if rng.random_sample() < 0.4:
+        sp = dna(rng.randint(2, 5)); segs.append("S:" + sp); parts.append(lambda sp=sp: sp)
+    if rng.random_sample() < 0.2:
+        segs.append("G:G"); parts.append(lambda: "G" * rng.randint(0, 4))
+    segs.append("R:N"); parts.append(lambda: dna(rng.randint(18, 70)))
+    if rng.random_sample() < 0.5:
+        p3 = dna(rng.randint(5, 24)); segs.append("P:" + p3); parts.append(lambda p3=p3: p3[:rng.randint(0, len(p3) + 1)])
+    return segs, parts
+
+
+@pytest.mark.parametrize("seed", list(range(20)))
+def test_random_architectures_against_oracle(ctx, seed):
+    """Model shapes beyond the fixtures: random segment lists (optional / partial / barcode / fingerprint / spacer / G /
+    read segments of random sizes), models from the library's own builder, reads with substitutions, indels, Ns and a
+    share of unrelated sequences; both kernels must equal the oracle bit for bit."""
+    from oracle import pyoracle
+    from tagdust_amd import lib as tdlib
+    rng = np.random.RandomState(1000 + seed)
+    segs, parts = _random_arch(rng)
+    code = {"A": 0, "C": 1, "G": 2, "T": 3, "N": 4}
+    reads = []
+    for i in range(400):
+        s_ = "".join(p() for p in parts)
+        out = []
+        for ch in s_:
+            u = rng.random_sample()
+            if u < 0.02:
+                out.append("ACGT"[rng.randint(4)])
+            elif u < 0.03:
+                continue
+            elif u < 0.04:
+                out.append(ch); out.append("ACGT"[rng.randint(4)])
+            elif u < 0.045:
+                out.append("N")
+            else:
+                out.append(ch)
+        s_ = "".join(out)
+        # (reads too short to have any path through the model are left out: the reference -- and with it the oracle --
+        # indexes its logsum table with a NaN there and crashes; the device's own rule for them is tested separately)
+        if rng.random_sample() < 0.1 or len(s_) < 12:
+            s_ = "".join("ACGT"[x] for x in rng.randint(0, 4, rng.randint(12, 90)))
+        reads.append(np.array([code[ch] for ch in s_], np.uint8))
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    seq = np.concatenate(reads)
+    md, _ = tdlib.build_model(segs, seq, offs, 0.05, 0.1)
+    thr = float(rng.choice([0.0, 1.5, 8.0]))
+    md.update(threshold=thr, minlen=int(rng.choice([8, 16])), dust=int(rng.choice([0, 100, 20])))
+    art, nthreads = None, 8
+    if seed % 3 == 1:   # an artifact filter on top: random sequences (some of them windows of reads), -fe, thread count
+        texts = []
+        for j in range(int(rng.randint(1, 5))):
+            if rng.random_sample() < 0.5:
+                r0 = reads[rng.randint(len(reads))]
+                texts.append(np.minimum(r0[-40:], 3))
+            else:
+                texts.append(rng.randint(0, 4, rng.randint(20, 120)).astype(np.uint8))
+        a_index = np.concatenate([[0], np.cumsum([len(t_) + 1 for t_ in texts])]).astype(np.int32)
+        a_string = np.concatenate([np.concatenate([[ord("X")], t_]) for t_ in texts]).astype(np.uint8)
+        nthreads = int(rng.randint(1, 6))
+        art = (a_string, a_index, int(rng.randint(2, 14)))
+        md["art_n"], md["art_string"], md["art_index"] = len(texts), a_string, a_index
+        md["art_filter_error"], md["art_threads"] = art[2], nthreads
+    ores, olab, oseq = pyoracle.label_batch(pyoracle.OracleModel(md), seq, offs, thr, int(md["minlen"]), int(md["dust"]),
+                                            nthreads, artifacts=art)
+    res, labels, seq_after = _run(ctx, md, seq, offs, threshold=thr)
+    for k in ("b_score", "f_score", "r_score", "bar_prob"):
+        assert np.array_equal(_bits(res[k]), _bits(ores[k])), (k, segs)
+    assert np.array_equal(labels, olab), segs
+    assert np.allclose(res["mapq"], ores["Q"], rtol=0, atol=Q_TOL), segs
+    for k in ("read_type", "barcode", "fingerprint"):
+        assert np.array_equal(res[k], ores[k]), (k, segs)
+    assert np.array_equal(seq_after, oseq), segs
