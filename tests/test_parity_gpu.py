@@ -412,7 +412,8 @@ def test_disk_cache_of_compiled_kernels(tmp_path, monkeypatch):
     from tagdust_amd import TagdustHip
     g = load_golden("umi_f_s_r")
     monkeypatch.setenv("TD_SPEC_CACHE_DIR", str(tmp_path))
-    monkeypatch.setenv("TD_SPEC_GROUPCOLS", "11")          # a variant no other test compiled: not in the in-memory cache
+    monkeypatch.setenv("TD_SPEC_NT", "0")                  # a source variant no other test compiled: not in the
+    monkeypatch.setenv("TD_SPEC_PAIR", "0")                # in-memory cache of this process
     c = TagdustHip(0)
     try:
         c.set_option("specialize", 1)
