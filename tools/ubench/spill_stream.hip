@@ -26,6 +26,26 @@ __global__ void __launch_bounds__(512) per_wave(float4* ws, size_t slot_f4, int 
 	if (acc.x == -1.0f) sink[0] = acc;
 }
 
+// the kernel's actual pattern: a group of NH HMMs, each with its own region of the slot; per position the wave writes
+// (then, in the second sweep, reads) PIECES KiB-pieces into each of the NH regions
+template <int NH, int PIECES>
+__global__ void __launch_bounds__(512) per_wave_streams(float4* ws, size_t slot_f4, int positions, float4* sink)
+{
+	const int lane = threadIdx.x & 63;
+	const size_t slot = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	float4* p = ws + slot * slot_f4;
+	const size_t region = slot_f4 / NH;
+	float4 v = make_float4(lane, 1.f, 2.f, 3.f);
+	for (int i = positions - 1; i >= 0; i--)
+		for (int h = 0; h < NH; h++)
+			for (int k = 0; k < PIECES; k++) { p[h * region + ((size_t)i * PIECES + k) * 64 + lane] = v; v.x += 1.0f; }
+	float4 acc = make_float4(0, 0, 0, 0);
+	for (int i = 0; i < positions; i++)
+		for (int h = 0; h < NH; h++)
+			for (int k = 0; k < PIECES; k++) { const float4 q = p[h * region + ((size_t)i * PIECES + k) * 64 + lane]; acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+	if (acc.x == -1.0f) sink[0] = acc;
+}
+
 __global__ void flat_copy(const float4* a, float4* b, size_t n)
 {
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
@@ -46,6 +66,20 @@ int main()
 		CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
 		float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
 		printf("per-wave regions, write then read: %.2f ms  %.2f TB/s\n", ms, bytes / ms / 1e9);
+	}
+	for (int rep = 0; rep < 2; rep++) {
+		CHK(hipEventRecord(e0));
+		hipLaunchKernelGGL((per_wave_streams<8, 3>), dim3(waves / 8), dim3(512), 0, 0, ws, slot_f4, pieces / 24, sink);
+		CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+		float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+		printf("8 streams x 3 KiB per position, backward then forward: %.2f ms  %.2f TB/s\n", ms, bytes / ms / 1e9);
+	}
+	for (int rep = 0; rep < 2; rep++) {
+		CHK(hipEventRecord(e0));
+		hipLaunchKernelGGL((per_wave_streams<1, 24>), dim3(waves / 8), dim3(512), 0, 0, ws, slot_f4, pieces / 24, sink);
+		CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+		float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+		printf("1 stream x 24 KiB per position, backward then forward:  %.2f ms  %.2f TB/s\n", ms, bytes / ms / 1e9);
 	}
 	{
 		const size_t n = slot_f4 * waves / 2;
