@@ -9,11 +9,11 @@
  *
  * i.e. the pthread fan-out over do_label_thread / do_probability_estimation (barcode_hmm.c:2174-2360), whose
  * per-read body is backward() (:3439) -> forward_max_posterior_decoding() (:4128) -> Q value (:2320-2338) ->
- * extract_reads() (:3172) -> dust_sequences() (:2407).  Plain C types only; every entry point returns
+ * extract_reads() (:3172) -> match_to_reference() (:2478, with -ref) -> dust_sequences() (:2407).  Plain C types only; every entry point returns
  * TD_OK (0) / TD_FAIL (1) like the reference's kslOK / kslFAIL (src/kslib.h:12-16) and never calls exit().
  * How a reference maintainer binds it is shown in INTEGRATION.md.
  *
- * Flow:  td_ctx_create -> td_model_upload -> td_set_params
+ * Flow:  td_ctx_create -> td_model_upload -> td_set_params [-> td_set_artifacts]
  *        per batch: td_batch_upload (host reads) -> td_run -> td_batch_download
  *        end of run: td_counts_get (per-outcome / per-barcode counters, the input of the RCCL all-reduce)
  */
