@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """End-to-end wall time, FASTQ file in -> demultiplexed FASTQ files out, through the library alone (parse, sequence
-statistics, model, threshold calibration with 400 000 simulated reads, decode, write) and -- when oracle/_ref/tagdust
-travelled with the snapshot -- through the reference binary on the same file, same -seed, all host threads.  The two
-runs must write identical files.   usage: tools/e2e_pipeline.py [n_reads] [--no-reference]"""
+statistics, model, threshold calibration with 400 000 simulated reads, decode, write) and -- when a TagDust2 binary is
+named with --reference PATH -- through that binary on the same file, same -seed, all host threads; the two runs must
+write identical files.   usage: tools/e2e_pipeline.py [n_reads] [--reference PATH]"""
 import glob
 import json
 import os
@@ -34,7 +34,7 @@ def write_fastq(path, reads):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1 << 20
-    with_ref = "--no-reference" not in sys.argv
+    exe = sys.argv[sys.argv.index("--reference") + 1] if "--reference" in sys.argv else None
     segs = ["B:" + ",".join(bench.BARCODES), "S:" + bench.SPACER, "R:N", "P:" + bench.ADAPTER]
     out = {"reads": n, "read_len": bench.READ_LEN, "arch": " ".join("-%d %s" % (k + 1, s) for k, s in enumerate(segs))}
     with tempfile.TemporaryDirectory() as tmp:
@@ -61,8 +61,7 @@ def main():
         t = time.perf_counter(); tdlib.write_demultiplexed(os.path.join(tmp, "own"), segs, pr, res, seq_out); st["write files"] = time.perf_counter() - t
         c.close()
         out["library"] = {"wall_s": time.perf_counter() - t0, "threshold": thr, "stages_s": {k: round(v, 3) for k, v in st.items()}}
-        exe = os.path.join(REPO, "oracle", "_ref", "tagdust")
-        if with_ref and os.path.exists(exe):
+        if exe and os.path.exists(exe):
             cores = min(len(os.sched_getaffinity(0)), 16)
             cmd = [exe, "-t", str(cores), "-seed", "42"]
             for k, s in enumerate(segs):
