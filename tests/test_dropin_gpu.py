@@ -163,3 +163,23 @@ def test_reference_cli_with_artifact_filter(tmp_path, threads):
         lines = open(os.path.join(str(tmp_path), prefix + "_logfile.txt")).read().splitlines()
         return sorted(l.split("\t", 1)[1] for l in lines if "artifact_" in l)   # drop the time stamp
     assert hits("cpu") == hits("gpu") and hits("cpu")
+
+
+@pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built")
+def test_config0_read_only_architecture(tmp_path):
+    """BASELINE.json configs[0]: '-1 R:N' (no barcode).  The label phase of such a run is run_rna_dust() (no HMM), but
+    the threshold calibration still pushes its simulated reads through run_pHMM(MODE_GET_PROB) with the one-HMM model:
+    the GPU-bound binary must select the same threshold and write the same files as the reference."""
+    d = str(tmp_path)
+    tags = os.path.join(REPO, "tests", "golden", "EDITTAG_6nt_ed_4_first4.txt")
+    _run("simreads_rtest", [tags, "-seed", "42", "-sim_barnum", "0", "-sim_readlen", "50", "-sim_readlen_mod", "0",
+                            "-sim_numseq", "3000", "-sim_endloss", "0", "-sim_random_frac", "0.1", "-sim_error_rate", "0.02",
+                            "-o", "c0.fq"], d)
+    _run("tagdust_rtest", ["-seed", "42", "-1", "R:N", "c0.fq", "-o", "cpu"], d)
+    log = _run("tagdust_hip_rtest", ["-seed", "42", "-1", "R:N", "c0.fq", "-o", "gpu"], d)
+    cpu, gpu = _outputs(d, "cpu"), _outputs(d, "gpu")
+    assert cpu and set(cpu) == set(gpu), (sorted(cpu), sorted(gpu), log[-1500:])
+    for k in cpu:
+        assert cpu[k] == gpu[k], "output file *%s differs" % k
+    thr = lambda p: [l.split("\t", 1)[1] for l in open(os.path.join(d, p + "_logfile.txt")).read().splitlines() if "selected threshold" in l]
+    assert thr("cpu") == thr("gpu") and thr("cpu")
