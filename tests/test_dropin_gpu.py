@@ -183,3 +183,36 @@ def test_config0_read_only_architecture(tmp_path):
         assert cpu[k] == gpu[k], "output file *%s differs" % k
     thr = lambda p: [l.split("\t", 1)[1] for l in open(os.path.join(d, p + "_logfile.txt")).read().splitlines() if "selected threshold" in l]
     assert thr("cpu") == thr("gpu") and thr("cpu")
+
+
+@pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built")
+def test_casava_three_file_run_with_arch_file(tmp_path):
+    """BASELINE.json configs[3] shape (dev/casava_test.sh; its read-1/read-3 files are not in the checkout, so they are
+    synthesised with matching CASAVA-1.8 names): three input files, '-arch' file with the index-read and the plain-read
+    architecture.  Per file the controller picks an architecture (MODE_ARCH_COMP on the GPU), the index file goes through
+    calibration and labelling on the GPU, the other two through run_rna_dust, and print_all combines them -- the
+    GPU-bound binary must write the same files as the reference."""
+    g = load_golden("casava_index")
+    d = str(tmp_path)
+    rng = np.random.RandomState(11)
+    names = bytes(g["names"]).split(b"\n")
+    offs = g["offs"]
+    with open(os.path.join(d, "r1.fq"), "wb") as f1, open(os.path.join(d, "r2.fq"), "wb") as f2, open(os.path.join(d, "r3.fq"), "wb") as f3:
+        for i in range(int(g["n_reads"])):
+            base = names[i].split(b" ")[0]
+            s2 = bytes(np.frombuffer(b"ACGTN", np.uint8)[g["seq"][offs[i]:offs[i + 1]]])
+            f2.write(b"@" + names[i] + b"\n" + s2 + b"\n+\n" + bytes(g["qual"][offs[i]:offs[i + 1]]) + b"\n")
+            for fh, k in ((f1, b"1"), (f3, b"3")):
+                s_ = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.randint(0, 4, 76)])
+                fh.write(b"@" + base + b" " + k + b":N:0:\n" + s_ + b"\n+\n" + b"I" * 76 + b"\n")
+    with open(os.path.join(d, "arch.txt"), "w") as fh:
+        fh.write("tagdust " + " ".join(str(g["cmdline"]).split()[2:]) + "\n")
+        fh.write("tagdust -1 R:N\n")
+    args = ["-seed", "42", "-arch", "arch.txt", "r1.fq", "r2.fq", "r3.fq"]
+    _run("tagdust_rtest", args + ["-o", "cpu"], d)
+    log = _run("tagdust_hip_rtest", args + ["-o", "gpu"], d)
+    cpu, gpu = _outputs(d, "cpu"), _outputs(d, "gpu")
+    assert len(cpu) > 4 and set(cpu) == set(gpu), (sorted(cpu), sorted(gpu), log[-1500:])
+    for k in cpu:
+        assert cpu[k] == gpu[k], "output file *%s differs" % k
+    assert any("_READ1" in k for k in cpu) and any("_READ2" in k for k in cpu)
