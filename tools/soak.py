@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Soak test of the C-ABI on the GPU: many batches of changing size / read length / model through one context (and a
+second context on another host thread), results compared with the first decode of the same reads, host and device
+memory watched for growth.   usage: tools/soak.py [iterations]"""
+import os
+import sys
+import threading
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from conftest import load_golden
+from tagdust_amd import TagdustHip
+
+
+def rss_mb():
+    for l in open("/proc/self/status"):
+        if l.startswith("VmRSS"):
+            return int(l.split()[1]) / 1024
+
+
+def worker(tag, iters, seed, errors):
+    rng = np.random.default_rng(seed)
+    fixtures = [load_golden(n) for n in ("c2_b4_r", "c3_b6_s_r_p", "umi_f_s_r", "scen2_endloss")]
+    c = TagdustHip(0)
+    ref = {}
+    try:
+        for it in range(iters):
+            k = int(rng.integers(len(fixtures)))
+            g = fixtures[k]
+            if it % 5 == 0 or "cur" not in ref or ref["cur"] != k:
+                c.set_option("specialize", int(rng.integers(0, 4) != 0))
+                c.upload_model(g)
+                c.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+                ref["cur"] = k
+            n_all = int(g["n_reads"])
+            n = int(rng.choice([0, 1, 63, 64, 65, n_all // 2, n_all]))
+            pick = np.sort(rng.choice(n_all, n, replace=False)) if n else np.zeros(0, np.int64)
+            reps = int(rng.choice([1, 1, 40, 400])) if n else 1          # sometimes a large batch of repeated reads
+            offs_g = g["offs"]
+            seqs = [g["seq"][offs_g[i]:offs_g[i + 1]] for i in pick] * reps
+            offs = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int64)
+            seq = np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)
+            c.upload_batch(seq, offs)
+            c.run()
+            res, labels, seq_after = c.download()
+            for r in range(0, reps, max(1, reps // 2)):
+                sl = slice(r * n, (r + 1) * n)
+                if not (np.array_equal(res["read_type"][sl], g["read_type"][pick]) and np.array_equal(res["barcode"][sl], g["barcode"][pick])
+                        and np.array_equal(res["f_score"][sl].view(np.uint32), g["f_score"][pick].astype(np.float32).view(np.uint32))):
+                    errors.append("%s: iteration %d fixture %d n %d reps %d differs" % (tag, it, k, n, reps))
+                    return
+    except Exception as e:                       # noqa: BLE001
+        errors.append("%s: %r" % (tag, e))
+    finally:
+        c.close()
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free0, tot = ctypes.c_size_t(), ctypes.c_size_t()
+    errors = []
+    worker("warm", 10, 0, errors)
+    hip.hipMemGetInfo(ctypes.byref(free0), ctypes.byref(tot))
+    r0 = rss_mb()
+    th = [threading.Thread(target=worker, args=("t%d" % t, iters, 100 + t, errors)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    free1 = ctypes.c_size_t()
+    hip.hipMemGetInfo(ctypes.byref(free1), ctypes.byref(tot))
+    print("iterations per thread:", iters, "errors:", errors)
+    print("device free before %.2f GB after %.2f GB; host RSS before %.0f MB after %.0f MB" % (free0.value / 1e9, free1.value / 1e9, r0, rss_mb()))
+    if errors or free0.value - free1.value > 1 << 30:
+        raise SystemExit(1)
+
+
+if __name__ == "__main__":
+    main()
