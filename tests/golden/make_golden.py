@@ -294,6 +294,31 @@ def scenarios(tmp):
         return fq, ["-seed", "42", "-1", "B:" + ",".join(bars), "-2", "P:CTGCA", "-3", "G:G", "-4", "R:N"]
     sc["b_intp_g_r"] = int_p
 
+    def dust():  # low-complexity inserts: DUST flags some reads (outcome 6), -dust 30
+        fq = os.path.join(tmp, "dust.fq")
+        rng = np.random.RandomState(29)
+        bars = read_tags(os.path.join(dev, "EDITTAG_4nt_ed_2.txt"), 4)
+        with open(fq, "w") as fh:
+            for i in range(240):
+                L = int(rng.randint(24, 90))
+                kind = i % 6
+                if kind == 0:
+                    ins = "ACGT"[rng.randint(4)] * L
+                elif kind == 1:
+                    u = "".join("ACGT"[k] for k in rng.randint(0, 4, 2)); ins = (u * L)[:L]
+                elif kind == 2:
+                    u = "".join("ACGT"[k] for k in rng.randint(0, 4, 3)); ins = (u * L)[:L]
+                elif kind == 3:   # random head, repetitive tail beyond the 64 characters DUST looks at
+                    ins = "".join("ACGT"[k] for k in rng.randint(0, 4, 66)) + "A" * 20
+                elif kind == 4:   # repetitive with a few substitutions
+                    ins = mutate(rng, "ACGT"[rng.randint(4)] * L, 0.1, 0.0)
+                else:
+                    ins = "".join("ACGT"[k] for k in rng.randint(0, 4, L))
+                s_ = bars[rng.randint(len(bars))] + ins
+                fh.write("@READ%d\n%s\n+\n%s\n" % (i, s_, "I" * len(s_)))
+        return fq, ["-seed", "42", "-dust", "30", "-1", "B:" + ",".join(bars), "-2", "R:N"]
+    sc["dust_b_r"] = dust
+
     def artifacts():  # -ref: artifact matching between extraction and DUST, 3 threads (4-groups + left-over reads)
         fq = os.path.join(tmp, "art.fq")
         fa = os.path.join(tmp, "art.fa")
