@@ -294,6 +294,22 @@ def scenarios(tmp):
         return fq, ["-seed", "42", "-1", "B:" + ",".join(bars), "-2", "P:CTGCA", "-3", "G:G", "-4", "R:N"]
     sc["b_intp_g_r"] = int_p
 
+    def two_reads():  # two read segments around a spacer: one input file, READ1 / READ2 output files
+        fq = os.path.join(tmp, "rr.fq")
+        rng = np.random.RandomState(31)
+        bars = ["ACAGTG", "CTTGTA", "GGCTAC"]
+        sp = "GATCGGAAGAGC"
+        with open(fq, "w") as fh:
+            for i in range(220):
+                a = "".join("ACGT"[k] for k in rng.randint(0, 4, rng.randint(10, 40)))     # some first reads shorter than -minlen
+                b2 = "".join("ACGT"[k] for k in rng.randint(0, 4, rng.randint(14, 45)))
+                s_ = bars[rng.randint(3)] + a + mutate(rng, sp, 0.03, 0.02) + b2
+                if rng.random_sample() < 0.1:
+                    s_ = "".join("ACGT"[k] for k in rng.randint(0, 4, len(s_)))
+                fh.write("@READ%d\n%s\n+\n%s\n" % (i, s_, "I" * len(s_)))
+        return fq, ["-seed", "42", "-1", "B:" + ",".join(bars), "-2", "R:N", "-3", "S:" + sp, "-4", "R:N"]
+    sc["b_r_s_r"] = two_reads
+
     def dust():  # low-complexity inserts: DUST flags some reads (outcome 6), -dust 30
         fq = os.path.join(tmp, "dust.fq")
         rng = np.random.RandomState(29)

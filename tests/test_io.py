@@ -13,7 +13,7 @@ from tagdust_amd import lib as tdlib
 
 RBIN = os.path.join(REPO, "oracle", "_ref")
 HAVE_REF = os.path.exists(os.path.join(RBIN, "tagdust_rtest"))
-NAMES = ["c2_b4_r", "c3_b6_s_r_p", "scen2_endloss", "umi_f_s_r", "short_q_given", "casava_index"]
+NAMES = ["c2_b4_r", "c3_b6_s_r_p", "scen2_endloss", "umi_f_s_r", "short_q_given", "casava_index", "b_r_s_r", "dust_b_r"]
 
 
 def fastq_text(g):
