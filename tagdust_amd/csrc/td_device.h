@@ -113,6 +113,8 @@ struct TdSpecLayout {
 	int64_t path;    // u32   [lmax][ceil(H/4)][64]   four path bytes per word
 	int64_t total;   // f32   [H][64]
 	int64_t dust;    // (unused)
+	int64_t bm;      // f32   [lmax+2][64]  running maximum of the first segment's label sums (kFirstN > 0)
+	int64_t ba;      // u8    [lmax+2][64]  the label holding it
 	int64_t acc;     // f32   [H][64]   label-DP row when H is too large for registers
 };
 

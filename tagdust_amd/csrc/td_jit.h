@@ -10,6 +10,7 @@ int td_spec_pure_last(const td_model_desc* m, int j, int col_off);
 int td_spec_rt_prefix(const td_model_desc* m, int j, int col_off, int8_t* base, float* hi, float* lo, float* nv);
 int td_spec_block_threads(void);
 int td_spec_min_waves(void);
+int td_spec_first_labels(const td_model_desc* m);   /* labels whose posteriors the forward sweep sums up itself (0: none) */
 int td_spec_lsum_oob(void);      /* 1: clamp-free logsum (LDS out-of-range reads as 0), see td_spec_kernel.inc */
 std::string td_spec_model_section(const td_model_desc* m, int lsum_oob = -1);   /* lsum_oob < 0: td_spec_lsum_oob() */
 std::string td_spec_full_source(const td_model_desc* m, int lsum_oob = -1);

@@ -517,3 +517,24 @@ def test_random_architectures_against_oracle(ctx, seed):
     for k in ("read_type", "barcode", "fingerprint"):
         assert np.array_equal(res[k], ores[k]), (k, segs)
     assert np.array_equal(seq_after, oseq), segs
+
+
+@pytest.mark.parametrize("name", ["c2_b4_r", "c3_b6_s_r_p", "scen2_p_b_r_p", "c2_indel_varlen", "b_r_s_r"])
+def test_first_segment_label_sums_forced(name, monkeypatch):
+    """The forward sweep can sum the posteriors of predecessor-free first-segment labels itself (used automatically for
+    models with more than 32 labels, e.g. config 5); forced on here for small models so that the scheme is covered on
+    the register path of the label DP as well."""
+    from tagdust_amd import TagdustHip
+    monkeypatch.setenv("TD_SPEC_FIRSTSEG", "1")
+    g = load_golden(name)
+    c = TagdustHip(0)
+    try:
+        c.set_option("specialize", 1)
+        res, labels, seq_after = _run(c, g)
+    finally:
+        c.close()
+    assert np.array_equal(labels, g["labels"])
+    for k in ("read_type", "barcode", "fingerprint"):
+        assert np.array_equal(res[k], g[k]), k
+    assert np.array_equal(seq_after, g["seq_after"])
+    assert np.array_equal(_bits(res["f_score"]), _bits(g["f_score"]))
