@@ -3,6 +3,8 @@
  (b) the CPU oracle on fresh seeded inputs.
 Bit-exact for labels / outcomes / barcodes / fingerprints / extracted sequences and for the float
 scores (f, b, r, bar_prob); Q within 1e-4 (BASELINE.json north_star) -- in practice also bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -455,7 +457,13 @@ def _random_arch(rng):
     return segs, parts
 
 
-@pytest.mark.parametrize("seed", list(range(20)))
+_FUZZ_SEEDS = list(range(20))
+if os.environ.get("TD_FUZZ_SEEDS"):      # e.g. TD_FUZZ_SEEDS=100:180 for a longer one-off run
+    _a, _b = os.environ["TD_FUZZ_SEEDS"].split(":")
+    _FUZZ_SEEDS = list(range(int(_a), int(_b)))
+
+
+@pytest.mark.parametrize("seed", _FUZZ_SEEDS)
 def test_random_architectures_against_oracle(ctx, seed):
     """Model shapes beyond the fixtures: random segment lists (optional / partial / barcode / fingerprint / spacer / G /
     read segments of random sizes), models from the library's own builder, reads with substitutions, indels, Ns and a
