@@ -72,7 +72,9 @@ typedef struct td_calibration {
 } td_calibration;
 
 /* n_reads: 400000 in the reference (4000 in its -DRTEST builds).  rng: 0 = srand(seed)/rand() of the C library,
- * 1 = the reference's private LCG of its -DRTEST builds (src/misc.c:878-887, RAND_MAX taken as 32768). */
+ * 1 = the reference's private LCG of its -DRTEST builds (src/misc.c:878-887, RAND_MAX taken as 32768).
+ * With rng 0 the process-wide rand() state is reseeded, as estimateQthreshold() does (calibrateQ.c:33); on glibc the
+ * numbers come from an inline copy of its generator that is checked against srand()/rand() once per process. */
 int   td_calibration_emit(const td_arch* arch, const td_seq_stats* stats, float indel_frequency, uint32_t seed,
                           int32_t n_reads, int32_t rng, td_calibration** out);
 /* the sort + sweep of calibrateQ.c:146-212 on the per-read Q values */
