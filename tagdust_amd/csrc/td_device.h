@@ -115,7 +115,7 @@ struct TdSpecLayout {
 	int64_t dust;    // (unused)
 	int64_t bm;      // f32   [lmax+2][64]  running maximum of the first segment's label sums (kFirstN > 0)
 	int64_t ba;      // u8    [lmax+2][64]  the label holding it
-	int64_t acc;     // f32   [H][64]   label-DP row when H is too large for registers
+	int64_t acc;     // f32   [2][H][64]  label-DP rows (previous / current position) when too many labels for registers
 };
 
 struct TdSpecArgs {
