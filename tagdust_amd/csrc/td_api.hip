@@ -20,8 +20,8 @@
 #include "td_device.h"
 #include "td_jit.h"
 
-extern "C" hipError_t td_launch_decode(const TdKernelArgs* ka, hipStream_t stream);
-extern "C" int td_kernel_block_threads(void);
+extern "C" __attribute__((visibility("hidden"))) hipError_t td_launch_decode(const TdKernelArgs* ka, hipStream_t stream);   // library-internal
+extern "C" __attribute__((visibility("hidden"))) int td_kernel_block_threads(void);
 
 static float g_logsum[TD_LOGSUM_SIZE];
 static bool g_logsum_ready = false;

@@ -779,11 +779,11 @@ __global__ __launch_bounds__(TD_BLOCK, 2) void td_decode_kernel(const TdKernelAr
 	}
 }
 
-extern "C" hipError_t td_launch_decode(const TdKernelArgs* ka, hipStream_t stream)
+extern "C" __attribute__((visibility("hidden"))) hipError_t td_launch_decode(const TdKernelArgs* ka, hipStream_t stream)
 {
 	const int blocks = (ka->n_slots + TD_WAVES_PER_BLOCK - 1) / TD_WAVES_PER_BLOCK;
 	hipLaunchKernelGGL(td_decode_kernel, dim3(blocks), dim3(TD_BLOCK), 0, stream, *ka);
 	return hipGetLastError();
 }
 
-extern "C" int td_kernel_block_threads(void) { return TD_BLOCK; }
+extern "C" __attribute__((visibility("hidden"))) int td_kernel_block_threads(void) { return TD_BLOCK; }

@@ -48,3 +48,17 @@ def test_no_cpu_fallback(library):
     with pytest.raises(tdlib.TdError) as e:
         tdlib.TagdustHip(0)
     assert "no CPU path" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_no_undeclared_c_entry_points(library):
+    """Every td_* C symbol the library exports is declared in include/*.h (internal helpers are hidden)."""
+    import re
+    import subprocess
+    from tagdust_amd import lib as tdlib
+    out = subprocess.run(["nm", "-D", "--defined-only", tdlib.LIB_PATH], stdout=subprocess.PIPE, check=True).stdout.decode()
+    exported = {l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T" and l.split()[2].startswith("td_")}
+    declared = set()
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    for h in os.listdir(inc):
+        declared |= set(re.findall(r"\b(td_[a-z_0-9]+)\s*\(", open(os.path.join(inc, h)).read()))
+    assert exported <= declared, sorted(exported - declared)
