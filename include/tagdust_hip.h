@@ -14,12 +14,19 @@
  * How a reference maintainer binds it is shown in INTEGRATION.md.
  *
  * Flow:  td_ctx_create -> td_model_upload -> td_set_params [-> td_set_artifacts]
- *        per batch: td_batch_upload (host reads) -> td_run -> td_batch_download
+ *        per batch: td_batch_upload (host reads) -> td_run -> td_batch_download          (one batch resident at a time)
+ *               or: td_submit (reads in, result buffers named) ... td_wait               (pipelined: the copies of the
+ *                   neighbouring batches overlap the decode kernel of the current one)
  *        end of run: td_counts_get (per-outcome / per-barcode counters, the input of the RCCL all-reduce)
+ *
+ * The host only moves contiguous bytes: base coding, the sort of the reads by length, 2-bit packing and, on the way back,
+ * the per-read records, the rewritten sequences and the labels in the caller's order are all produced on the device.
+ * A context is not thread-safe: drive it from one host thread (one context per GPU, like one model copy per pthread).
  */
 #ifndef TAGDUST_HIP_H
 #define TAGDUST_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -105,10 +112,11 @@ const float* td_logsum_table(void);
 /* Uploads the tables and (option "specialize", default 1) compiles the decode kernel specialised for this
  * model with hiprtc -- a few seconds, once per architecture.  A compile failure is TD_FAIL, not a fallback. */
 int td_model_upload(td_ctx* ctx, const td_model_desc* model);
-/* Options, set before td_model_upload:  "specialize" 1 = model-specialised kernel (default; env TD_SPECIALIZE),
- * 0 = the generic ahead-of-time kernel that reads the model from HBM. */
+/* Options:  "specialize" (set before td_model_upload) 1 = model-specialised kernel (default; env TD_SPECIALIZE),
+ * 0 = the generic ahead-of-time kernel that reads the model from HBM;  "pipeline_depth" 1..4 (default 2) = batches
+ * td_submit may hold in flight. */
 int td_set_option(td_ctx* ctx, const char* name, int32_t value);
-/* Read a setting back: "specialize", or "spec_lsum_clamped" (1 when the loaded specialised kernel uses the clamped
+/* Read a setting back: "specialize", "pipeline_depth", or "spec_lsum_clamped" (1 when the loaded specialised kernel uses the clamped
  * logsum: the clamp-free form is only selected while model parameters x read length bound every score difference). */
 int td_get_option(td_ctx* ctx, const char* name, int32_t* value);
 /* The HIP source td_model_upload would compile for this model (no GPU needed).  Returns its length; copies at
@@ -127,8 +135,9 @@ int td_set_params(td_ctx* ctx, float threshold, int32_t minlen, int32_t dust);
 
 /* ---- batches ---- */
 /* Stage a batch of reads: codes = base codes 0..4 (A,C,G,T,other: src/nuc_code.c:46-74) of all reads
- * concatenated, offs[n_reads+1] the read boundaries (like ri[i]->seq / ri[i]->len).  Packs to 2 bit + N mask,
- * copies to HBM.  Replaces whatever batch was resident. */
+ * concatenated, offs[n_reads+1] the read boundaries (like ri[i]->seq / ri[i]->len; offs[0] = 0).  One host-to-device
+ * copy of the bytes as they are; sorting by length and packing to 2 bit + N mask happen on the device.  Replaces
+ * whatever batch was resident; returns when the caller's buffers may be reused. */
 int td_batch_upload(td_ctx* ctx, const uint8_t* codes, const int64_t* offs, int64_t n_reads);
 /* Same from ASCII FASTQ sequence lines (applies the nuc_code mapping). */
 int td_batch_upload_ascii(td_ctx* ctx, const char* bases, const int64_t* offs, int64_t n_reads);
@@ -144,6 +153,22 @@ int td_sync(td_ctx* ctx);
  *            (codes 0..4, non-read positions 65; barcode_hmm.c:3325-3356); untouched codes when not extracted */
 int td_batch_download(td_ctx* ctx, td_read_result* res, int8_t* labels, uint8_t* seq_out);
 
+/* ---- pipelined batches: one run_pHMM call per batch (barcode_hmm.c:322), several batches in flight ---- */
+/* Hand over a batch and name where its results go; returns once the reads have left the caller's buffers (they may be
+ * reused) with the upload, the decode kernel (mode as td_run; parameters, model and artifact filter as set at this
+ * moment) and the download queued on the device.  bases: base codes 0..4, or FASTQ sequence text when is_ascii != 0.
+ * res / labels / seq_out as in td_batch_download (any may be NULL); they are complete after td_wait(ticket).
+ * At most "pipeline_depth" tickets may be outstanding (TD_FAIL beyond that).  Page-locked buffers (td_host_alloc, or
+ * registered with hipHostRegister) are read and written by the DMA engines directly; any other host memory goes through
+ * the library's own pinned staging with one extra host copy each way (TD_HOST_THREADS host threads, default all, <= 16). */
+int td_submit(td_ctx* ctx, const void* bases, int32_t is_ascii, const int64_t* offs, int64_t n_reads, int mode,
+              td_read_result* res, int8_t* labels, uint8_t* seq_out, int64_t* ticket);
+/* Block until the batch of this ticket is complete and its results are in the buffers named at td_submit. */
+int td_wait(td_ctx* ctx, int64_t ticket);
+/* Page-locked host memory for batch inputs / outputs (NULL on failure). */
+void* td_host_alloc(size_t bytes);
+void  td_host_free(void* p);
+
 /* ---- counters (the reference's serial outcome counting, barcode_hmm.c:354-384, done on device) ---- */
 int td_counts_reset(td_ctx* ctx);
 int td_counts_get(td_ctx* ctx, int64_t* counts /* [TD_NUM_COUNTERS] */);
@@ -151,7 +176,8 @@ int td_counts_get(td_ctx* ctx, int64_t* counts /* [TD_NUM_COUNTERS] */);
 void* td_counts_device_ptr(td_ctx* ctx);
 
 /* ---- measurement hooks (bench.py) ---- */
-/* Milliseconds the last td_run's kernel took, from HIP events recorded on the context's stream. */
+/* Milliseconds the decode kernel of the last td_run -- or of the batch last td_wait'ed for -- took, from HIP events
+ * recorded around it on the context's compute stream. */
 int td_last_kernel_ms(td_ctx* ctx, float* ms);
 /* Number of reads resident, HBM workspace bytes, wave slots in use. */
 int td_batch_info(td_ctx* ctx, int64_t* n_reads, int64_t* workspace_bytes, int32_t* wave_slots);

@@ -19,6 +19,7 @@
 #include "../../include/tagdust_hip.h"
 #include "td_device.h"
 #include "td_jit.h"
+#include "td_stage.h"
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t td_launch_decode(const TdKernelArgs* ka, hipStream_t stream);   // library-internal
 extern "C" __attribute__((visibility("hidden"))) int td_kernel_block_threads(void);
@@ -38,10 +39,51 @@ static void init_logsum_host()
 // prob2scaledprob(), src/misc.c:85-92
 static float p2sp(float p) { return p == 0.0f ? -INFINITY : (float)log((double)p); }
 
+#define TD_MAX_PIPELINE 4
+
+// One batch on its way through the device (see "batches" below).
+struct TdSlot {
+	int64_t n_reads = 0, n_bases = 0;
+	int32_t n_tiles = 0, lmax = 0, nw2 = 0, nw1 = 0;
+	int is_ascii = 0, mode = 0;
+	bool sorted = false;      // device order differs from the caller's (reads of several lengths)
+	bool staged = false;      // inputs are packed on the device: td_run may launch
+	bool ran = false, finished = false;
+	float last_ms = -1.0f;
+	int64_t ticket = 0;       // td_submit: 0 = free
+	td_read_result* u_res = nullptr; int8_t* u_labels = nullptr; uint8_t* u_seq = nullptr;   // the caller's output buffers
+	bool res_direct = false, lab_direct = false, seq_direct = false;                          // ... are page-locked
+	TdStageBatch sb{};
+	TdWsLayout lay{};
+	TdSpecLayout slay{};
+	int32_t n_wave_slots = 0;
+	int64_t ws_slot_bytes = 0;
+	// device
+	uint8_t* d_raw = nullptr;      size_t cap_raw = 0;
+	int64_t* d_offs = nullptr;     size_t cap_offs = 0;
+	int32_t* d_read_at = nullptr;  size_t cap_read_at = 0;
+	uint32_t* d_keys = nullptr;    size_t cap_keys = 0;
+	int32_t* d_vals = nullptr;     size_t cap_vals = 0;
+	uint8_t* d_sort_tmp = nullptr; size_t cap_sort_tmp = 0;
+	uint32_t* d_packed = nullptr;  size_t cap_packed = 0;
+	int32_t* d_lens = nullptr;     size_t cap_lens = 0;
+	uint8_t* d_art_left = nullptr; size_t cap_art_left = 0;
+	uint8_t* d_out = nullptr;      size_t cap_out = 0;    // decode-kernel outputs, device order
+	uint8_t* d_res = nullptr;      size_t cap_res = 0;    // results in the caller's order
+	uint8_t* d_seq = nullptr;      size_t cap_seq = 0;
+	int8_t*  d_lab = nullptr;      size_t cap_lab = 0;
+	// pinned host staging for pageable caller memory
+	uint8_t* h_raw = nullptr;      size_t cap_h_raw = 0;
+	int64_t* h_offs = nullptr;     size_t cap_h_offs = 0;
+	uint8_t* h_res = nullptr;      size_t cap_h_res = 0;
+	uint8_t* h_seq = nullptr;      size_t cap_h_seq = 0;
+	int8_t*  h_lab = nullptr;      size_t cap_h_lab = 0;
+	hipEvent_t ev_up = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr, ev_down = nullptr;
+};
+
 struct td_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	std::string err;
 	int n_cu = 0;
 	size_t hbm_total = 0;
@@ -72,46 +114,39 @@ struct td_ctx {
 	std::vector<int32_t> m_finger_len;
 	bool spec_oob = false;      // the loaded kernel uses the clamp-free logsum
 	float m_maxabs = 0.0f;      // largest |finite parameter|
-	TdSpecLayout slay{};
 	int spec_block = 256, spec_waves_per_cu = 8;
 
 	// params
 	float threshold = 0.0f;
 	int32_t minlen = 16, dust = 100;
 
-	// batch
-	int64_t n_reads = 0;
-	int32_t n_tiles = 0, lmax = 0, nw2 = 0, nw1 = 0;
-	std::vector<int64_t> offs;
-	std::vector<uint8_t> codes_host; // kept for td_batch_download(seq_out)
-	std::vector<int64_t> pos_of;     // pos_of[i] = position of read i in the length-sorted device order
-	uint32_t* d_packed = nullptr; size_t cap_packed = 0;
-	int32_t* d_lens = nullptr;    size_t cap_lens = 0;
-	// pinned host staging (H2D of the packed batch, D2H of the outputs): pageable copies run at a fraction of the link
-	// rate and a fresh std::vector per batch is zero-filled first
-	uint32_t* h_packed = nullptr; size_t cap_h_packed = 0;
-	int32_t*  h_lens = nullptr;   size_t cap_h_lens = 0;
-	uint8_t*  h_out = nullptr;    size_t cap_h_out = 0;
 	// -ref artifact filter
 	uint8_t* d_art_text = nullptr; int32_t* d_art_index = nullptr;
-	uint8_t* d_art_left = nullptr; size_t cap_art_left = 0;
 	int32_t art_n = 0, art_fe = 0, art_threads = 1;
-	uint8_t* d_out = nullptr;     size_t cap_out = 0;   // all per-read outputs in one allocation
-	uint8_t* d_ws = nullptr;      size_t cap_ws = 0;
-	TdWsLayout lay{};
-	int32_t n_slots = 0;
-	bool ran = false;
-	float last_ms = -1.0f;
+	// batches: slot 0 is the resident batch of the synchronous calls; td_submit rotates over pipeline_depth slots
+	TdSlot slots[TD_MAX_PIPELINE];
+	int pipeline_depth = 2, next_slot = 0, last_slot = 0;
+	int64_t ticket_counter = 0;
+	hipStream_t s_up = nullptr, s_down = nullptr;   // copy streams of the pipelined calls
+	uint8_t* d_ws = nullptr;      size_t cap_ws = 0;  // one workspace for all slots (decode kernels run one after the other)
 };
 
-// run fn(lo, hi) over [0, n) on up to 16 host threads (TD_HOST_THREADS overrides)
-template <typename F>
-static void parallel_ranges(int64_t n, F fn)
+// host threads the library may use for its own copies (TD_HOST_THREADS overrides; at most 16)
+static int host_threads()
 {
 	int nt = (int)std::thread::hardware_concurrency();
 	if (const char* e = getenv("TD_HOST_THREADS")) nt = atoi(e);
 	if (nt > 16) nt = 16;
-	if (nt < 1 || n < 65536) nt = 1;
+	if (nt < 1) nt = 1;
+	return nt;
+}
+
+// run fn(lo, hi) over [0, n) on the host threads
+template <typename F>
+static void parallel_ranges(int64_t n, F fn)
+{
+	int nt = host_threads();
+	if (n < 65536) nt = 1;
 	if (nt == 1) { fn((int64_t)0, n); return; }
 	std::vector<std::thread> th;
 	const int64_t per = (n + nt - 1) / nt;
@@ -200,7 +235,6 @@ extern "C" int td_ctx_create(int device, td_ctx** out)
 	c->hbm_total = prop.totalGlobalMem;
 	init_logsum_host();
 	bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-	          hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
 	          hipMalloc((void**)&c->d_logsum, sizeof(float) * TD_LOGSUM_LIVE) == hipSuccess &&
 	          hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * TD_NUM_COUNTERS) == hipSuccess &&
 	          hipMemcpy(c->d_logsum, g_logsum, sizeof(float) * TD_LOGSUM_LIVE, hipMemcpyHostToDevice) == hipSuccess &&
@@ -213,19 +247,23 @@ extern "C" int td_ctx_create(int device, td_ctx** out)
 	return TD_OK;
 }
 
+static void slot_release(TdSlot& s);
+static bool tickets_outstanding(const td_ctx* c);
+
 extern "C" void td_ctx_destroy(td_ctx* c)
 {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->s_up) (void)hipStreamSynchronize(c->s_up);
+	if (c->s_down) (void)hipStreamSynchronize(c->s_down);
 	void* bufs[] = { c->d_hdr, c->d_cols, c->d_hinfo, c->d_pred_off, c->d_pred_idx, c->d_logsum, c->d_counters,
-	                 c->d_packed, c->d_lens, c->d_out, c->d_ws, c->d_art_text, c->d_art_index, c->d_art_left };
+	                 c->d_ws, c->d_art_text, c->d_art_index };
 	for (void* p : bufs) if (p) (void)hipFree(p);
-	void* pinned[] = { c->h_packed, c->h_lens, c->h_out };
-	for (void* p : pinned) if (p) (void)hipHostFree(p);
+	for (int k = 0; k < TD_MAX_PIPELINE; k++) slot_release(c->slots[k]);
+	if (c->s_up) (void)hipStreamDestroy(c->s_up);
+	if (c->s_down) (void)hipStreamDestroy(c->s_down);
 	if (c->spec_mod) (void)hipModuleUnload(c->spec_mod);
-	if (c->ev0) (void)hipEventDestroy(c->ev0);
-	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -321,10 +359,14 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 	poff[m->H] = (int32_t)pidx.size();
 	if (pidx.empty()) pidx.push_back(0);
 
+	// from here on the context holds no usable model / batch until every step below has succeeded
+	c->have_model = false;
+	for (int k = 0; k < TD_MAX_PIPELINE; k++) { c->slots[k].staged = false; c->slots[k].ran = false; }   // batches are staged per model
+	if (tickets_outstanding(c)) return fail(c, "td_model_upload: td_submit tickets are outstanding (td_wait them first)");
+	HIPCHK(c, hipStreamSynchronize(c->stream));
 	void* old[] = { c->d_hdr, c->d_cols, c->d_hinfo, c->d_pred_off, c->d_pred_idx };
 	for (void* p : old) if (p) HIPCHK(c, hipFree(p));
 	c->d_hdr = nullptr; c->d_cols = nullptr; c->d_hinfo = nullptr; c->d_pred_off = nullptr; c->d_pred_idx = nullptr;
-	c->have_model = false;
 	HIPCHK(c, hipMalloc((void**)&c->d_hdr, sizeof h));
 	HIPCHK(c, hipMalloc((void**)&c->d_cols, sizeof(TdCol) * cols.size()));
 	HIPCHK(c, hipMalloc((void**)&c->d_hinfo, sizeof(uint32_t) * hinfo.size()));
@@ -340,9 +382,6 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 	c->m_n_hmm.assign(m->n_hmm, m->n_hmm + m->S);
 	c->m_n_col.assign(m->n_col, m->n_col + m->S);
 	c->m_trans.assign(m->trans, m->trans + (size_t)m->C * 9);
-	c->have_model = true;
-	c->ran = false;
-	c->n_reads = 0; c->n_tiles = 0;
 
 	// model-specialised kernel: compile now (seconds); a failure is an error, never a silent fallback
 	if (c->spec_mod) { HIPCHK(c, hipModuleUnload(c->spec_mod)); c->spec_mod = nullptr; }
@@ -378,6 +417,7 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 		const int by_regs = 4 * td_spec_min_waves();
 		if (c->spec_waves_per_cu > by_regs) c->spec_waves_per_cu = by_regs;
 	}
+	c->have_model = true;
 	return TD_OK;
 }
 
@@ -388,6 +428,12 @@ extern "C" int td_set_option(td_ctx* c, const char* name, int32_t value)
 		c->specialize = value != 0; // takes effect at the next td_model_upload
 		return TD_OK;
 	}
+	if (!strcmp(name, "pipeline_depth")) {
+		if (value < 1 || value > TD_MAX_PIPELINE) return fail(c, "td_set_option: pipeline_depth must be 1..%d", TD_MAX_PIPELINE);
+		if (tickets_outstanding(c)) return fail(c, "td_set_option: pipeline_depth cannot change while tickets are outstanding");
+		c->pipeline_depth = value; c->next_slot = 0;
+		return TD_OK;
+	}
 	return fail(c, "td_set_option: unknown option %s", name);
 }
 
@@ -396,6 +442,7 @@ extern "C" int td_get_option(td_ctx* c, const char* name, int32_t* value)
 	if (!c || !name || !value) return TD_FAIL;
 	if (!strcmp(name, "specialize")) { *value = c->specialize; return TD_OK; }
 	if (!strcmp(name, "spec_lsum_clamped")) { *value = c->spec_ready && !c->spec_oob; return TD_OK; }
+	if (!strcmp(name, "pipeline_depth")) { *value = c->pipeline_depth; return TD_OK; }
 	return fail(c, "td_get_option: unknown option %s", name);
 }
 
@@ -431,6 +478,13 @@ extern "C" int td_set_params(td_ctx* c, float threshold, int32_t minlen, int32_t
 // ---------------------------------------------------------------------------------------------------------
 // batches
 // ---------------------------------------------------------------------------------------------------------
+// A batch lives in a slot.  The host hands over the reads as they are (base codes or FASTQ sequence text + offsets) and
+// gets per-read records, rewritten sequences and labels back in the same order; everything in between -- base coding,
+// the stable sort by length, 2-bit packing and lane interleave, and on the way back un-permuting and de-interleaving --
+// runs on the device (td_stage.hip), so a transfer is one copy of contiguous bytes each way.  The synchronous calls
+// (td_batch_upload / td_run / td_batch_download) work on slot 0; td_submit / td_wait rotate over `pipeline_depth` slots
+// with the copies on their own streams, so that the upload of batch k+1 and the download of batch k-1 overlap the decode
+// kernel of batch k.  One HBM workspace serves all slots (decode kernels are serialised on the compute stream).
 static inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
 static void make_layout(TdWsLayout& L, int S, int H, int C, int lmax, int max_ncol)
@@ -449,179 +503,221 @@ static void make_layout(TdWsLayout& L, int S, int H, int C, int lmax, int max_nc
 	L.slot_bytes = o;
 }
 
-// output block: SoA arrays over n_tiles*64 reads, then keep words, then labels
-struct OutLayout { int64_t f, b, r, bar, q, type, barcode, finger, keep, labels, total; };
+// output block of the decode kernels: eight SoA arrays over n_tiles*64 reads (f, b, r, bar, q, type, barcode, finger: equal
+// strides), then keep words, then labels -- all in device order
+struct OutLayout { int64_t soa_stride, keep, labels, total; };
 static OutLayout out_layout(int64_t n_tiles, int lmax, int nw1)
 {
-	OutLayout o; int64_t p = 0; const int64_t n = n_tiles * TD_WAVE;
-	o.f = p; p = align256(p + n * 4); o.b = p; p = align256(p + n * 4); o.r = p; p = align256(p + n * 4);
-	o.bar = p; p = align256(p + n * 4); o.q = p; p = align256(p + n * 4); o.type = p; p = align256(p + n * 4);
-	o.barcode = p; p = align256(p + n * 4); o.finger = p; p = align256(p + n * 4);
+	OutLayout o;
+	o.soa_stride = n_tiles * TD_WAVE * 4;      // a multiple of 256
+	int64_t p = 8 * o.soa_stride;
 	o.keep = p; p = align256(p + n_tiles * nw1 * TD_WAVE * 4);
 	o.labels = p; p = align256(p + n_tiles * (int64_t)(lmax + 1) * TD_WAVE);
 	o.total = p;
 	return o;
 }
 
-static int upload_common(td_ctx* c, const uint8_t* codes, const char* ascii, const int64_t* offs, int64_t n)
+// is this host pointer page-locked (hipHostMalloc / hipHostRegister)?  Then the DMA engines can use it directly.
+static bool is_pinned(const void* p)
 {
-	if (!c) return TD_FAIL;
-	if (!c->have_model) return fail(c, "td_batch_upload: no model uploaded");
-	if ((!codes && !ascii) || !offs || n < 0) return fail(c, "td_batch_upload: bad arguments");
-	HIPCHK(c, hipSetDevice(c->device));
-	int lmax = 1;
-	for (int64_t i = 0; i < n; i++) {
-		const int64_t l = offs[i + 1] - offs[i];
-		if (l < 0 || l > 100000) return fail(c, "td_batch_upload: read %lld has length %lld", (long long)i, (long long)l);
-		if (l > lmax) lmax = (int)l;
+	if (!p) return false;
+	hipPointerAttribute_t a;
+	if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+	return a.type == hipMemoryTypeHost;
+}
+
+// memcpy on the library's host threads (pageable caller memory <-> pinned staging)
+static void parallel_copy(void* dst, const void* src, size_t bytes)
+{
+	const int64_t chunk = 1 << 20;
+	const int64_t nchunks = (int64_t)((bytes + chunk - 1) / chunk);
+	if (nchunks <= 4) { memcpy(dst, src, bytes); return; }
+	int nt = host_threads();
+	if (nt > nchunks) nt = (int)nchunks;
+	if (nt <= 1) { memcpy(dst, src, bytes); return; }
+	std::vector<std::thread> th;
+	const int64_t per = (nchunks + nt - 1) / nt;
+	for (int t = 0; t < nt; t++) {
+		const size_t lo = (size_t)(t * per * chunk);
+		size_t hi = (size_t)((t + 1) * per * chunk);
+		if (hi > bytes) hi = bytes;
+		if (lo < hi) th.emplace_back([=] { memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
 	}
-	const int64_t n_tiles = (n + TD_WAVE - 1) / TD_WAVE;
-	const int nw2 = (lmax + 15) / 16, nw1 = (lmax + 31) / 32;
-	const int64_t tile_words = (int64_t)(nw2 + nw1) * TD_WAVE;
+	for (auto& t : th) t.join();
+}
 
-	// pack: 2 bits per base + 1 bit "is N" per base, lane-interleaved per tile so a wave reads 256 contiguous bytes per word
-	const size_t n_packed = (size_t)(n_tiles * tile_words), n_lens = (size_t)(n_tiles * TD_WAVE);
-	if (ensure_pinned(c, &c->h_packed, &c->cap_h_packed, n_packed * 4) != TD_OK) return TD_FAIL;
-	if (ensure_pinned(c, &c->h_lens, &c->cap_h_lens, n_lens * 4) != TD_OK) return TD_FAIL;
-	uint32_t* const packed = c->h_packed;
-	int32_t* const lens = c->h_lens;
-	parallel_ranges((int64_t)n_packed, [&](int64_t lo, int64_t hi) { memset(packed + lo, 0, (size_t)(hi - lo) * 4); });
-	memset(lens, 0, n_lens * 4);
-	c->codes_host.resize((size_t)offs[n]);
-	// init_nuc_code(), src/nuc_code.c:46-74: ACGTU (either case) -> 0..3(3), everything else 4 (thread-safe static init)
-	struct AscTable {
-		uint8_t t[256];
-		AscTable()
-		{
-			for (int k = 0; k < 256; k++) t[k] = 4;
-			t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3; t['U'] = t['u'] = 3;
-		}
-	};
-	static const AscTable asc_table;
-	const uint8_t* asc2code = asc_table.t;
-	// Reads are laid out on the device sorted by length (stable counting sort), so that the 64 reads of a tile have
-	// (nearly) the same length and no lane idles through another read's extra positions; results are un-permuted on
-	// download.  Per-read results do not depend on the order (every read is decoded independently).
-	c->pos_of.assign((size_t)n, 0);
-	{
-		std::vector<int64_t> start((size_t)lmax + 2, 0);
-		for (int64_t i = 0; i < n; i++) start[(size_t)(offs[i + 1] - offs[i]) + 1]++;
-		for (int l = 0; l <= lmax; l++) start[(size_t)l + 1] += start[(size_t)l];
-		for (int64_t i = 0; i < n; i++) c->pos_of[(size_t)i] = start[(size_t)(offs[i + 1] - offs[i])]++;
-	}
-	// every read owns its (tile, lane) words, so reads can be packed by several host threads without synchronisation
-	auto pack_range = [&](int64_t lo, int64_t hi) {
-		for (int64_t i = lo; i < hi; i++) {
-			const int64_t k = c->pos_of[(size_t)i];
-			const int64_t tile = k / TD_WAVE; const int lane = (int)(k % TD_WAVE);
-			const int l = (int)(offs[i + 1] - offs[i]);
-			lens[(size_t)k] = l;
-			uint32_t* pk = packed + tile * tile_words;
-			uint32_t w2 = 0, w1 = 0;   // a word is built in a register and stored once
-			for (int kk = 0; kk < l; kk++) {
-				uint8_t cd = codes ? codes[offs[i] + kk] : asc2code[(uint8_t)ascii[offs[i] + kk]];
-				if (cd > 4) cd = 4;
-				c->codes_host[(size_t)(offs[i] + kk)] = cd;
-				if (cd == 4) w1 |= 1u << (kk & 31);
-				else w2 |= (uint32_t)cd << (2 * (kk & 15));
-				if ((kk & 15) == 15 || kk == l - 1) { pk[(kk >> 4) * TD_WAVE + lane] = w2; w2 = 0; }
-				if ((kk & 31) == 31 || kk == l - 1) { pk[(nw2 + (kk >> 5)) * TD_WAVE + lane] = w1; w1 = 0; }
-			}
-		}
-	};
-	parallel_ranges(n, pack_range);
-	if (ensure(c, &c->d_packed, &c->cap_packed, n_packed * 4) != TD_OK) return TD_FAIL;
-	if (ensure(c, &c->d_lens, &c->cap_lens, n_lens * 4) != TD_OK) return TD_FAIL;
-	if (n_packed) HIPCHK(c, hipMemcpyAsync(c->d_packed, packed, n_packed * 4, hipMemcpyHostToDevice, c->stream));
-	if (n_lens) HIPCHK(c, hipMemcpyAsync(c->d_lens, lens, n_lens * 4, hipMemcpyHostToDevice, c->stream));
-	HIPCHK(c, hipStreamSynchronize(c->stream));
+static int slot_events(td_ctx* c, TdSlot& s)
+{
+	if (s.ev_k0) return TD_OK;
+	HIPCHK(c, hipEventCreate(&s.ev_k0));
+	HIPCHK(c, hipEventCreate(&s.ev_k1));
+	HIPCHK(c, hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
+	HIPCHK(c, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+	HIPCHK(c, hipEventCreateWithFlags(&s.ev_down, hipEventDisableTiming));
+	return TD_OK;
+}
 
-	c->n_reads = n; c->n_tiles = (int32_t)n_tiles; c->lmax = lmax; c->nw2 = nw2; c->nw1 = nw1;
-	c->offs.assign(offs, offs + n + 1);
-	c->ran = false;
+static void slot_release(TdSlot& s)
+{
+	void* dev[] = { s.d_raw, s.d_offs, s.d_read_at, s.d_keys, s.d_vals, s.d_sort_tmp, s.d_packed, s.d_lens, s.d_art_left,
+	                s.d_out, s.d_res, s.d_seq, s.d_lab };
+	for (void* p : dev) if (p) (void)hipFree(p);
+	void* pinned[] = { s.h_raw, s.h_offs, s.h_res, s.h_seq, s.h_lab };
+	for (void* p : pinned) if (p) (void)hipHostFree(p);
+	hipEvent_t ev[] = { s.ev_up, s.ev_k0, s.ev_k1, s.ev_done, s.ev_down };
+	for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+	s = TdSlot();
+}
 
-	// outputs + workspace
-	const OutLayout ol = out_layout(n_tiles, lmax, nw1);
-	if (ensure(c, &c->d_out, &c->cap_out, (size_t)ol.total) != TD_OK) return TD_FAIL;
-	make_layout(c->lay, c->hdr.S, c->hdr.H, c->hdr.C, lmax, c->hdr.max_ncol);
-	int64_t slot_bytes = c->lay.slot_bytes;
-	if (c->spec_ready && c->spec_oob && !spec_lsum_range_ok(c, lmax)) {
+// Size the shared workspace for a batch with this geometry.  Growing it (or switching the kernel to the clamped logsum)
+// waits for the decode kernels in flight first.
+static int ensure_workspace(td_ctx* c, TdSlot& s)
+{
+	make_layout(s.lay, c->hdr.S, c->hdr.H, c->hdr.C, s.lmax, c->hdr.max_ncol);
+	int64_t slot_bytes = s.lay.slot_bytes;
+	if (c->spec_ready && c->spec_oob && !spec_lsum_range_ok(c, s.lmax)) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
 		if (load_spec_kernel(c, 0) != TD_OK) return TD_FAIL;   // reads this long need the clamped logsum (seconds, once)
 	}
 	if (c->spec_ready) {
 		td_model_desc md{};
 		md.S = c->hdr.S; md.H = c->hdr.H; md.C = c->hdr.C;
 		md.n_hmm = c->m_n_hmm.data(); md.n_col = c->m_n_col.data(); md.trans = c->m_trans.data();
-		td_spec_layout(c->slay, &md, lmax);
-		slot_bytes = c->slay.slot_bytes;
+		td_spec_layout(s.slay, &md, s.lmax);
+		slot_bytes = s.slay.slot_bytes;
 	}
 	// wave slots: enough to fill the chip (2 workgroups of 4 waves per CU share the LDS), bounded by HBM
 	const int wpb = (c->spec_ready ? c->spec_block : td_kernel_block_threads()) / TD_WAVE;
 	int64_t want = (int64_t)c->n_cu * (c->spec_ready ? c->spec_waves_per_cu : 2 * wpb);
 	if (const char* e = getenv("TD_WAVE_SLOTS")) { const long v = atol(e); if (v > 0) want = v; }
-	size_t free_b = 0, total_b = 0;
-	HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-	const int64_t budget = (int64_t)((double)(free_b + c->cap_ws) * 0.85);
 	int64_t slots = want;
-	if (slots * slot_bytes > budget) slots = budget / slot_bytes;
-	if (slots > n_tiles) slots = n_tiles;
-	if (slots < 1) {
-		if (n_tiles == 0) slots = 1;
-		else return fail(c, "td_batch_upload: workspace of %lld bytes per wave does not fit in HBM", (long long)slot_bytes);
-	}
+	if (slots > s.n_tiles) slots = s.n_tiles;
+	if (slots < 1) slots = 1;
 	slots = (slots + wpb - 1) / wpb * wpb; // whole workgroups
-	if (ensure(c, &c->d_ws, &c->cap_ws, (size_t)(slots * slot_bytes)) != TD_OK) return TD_FAIL;
-	c->n_slots = (int32_t)slots;
+	if ((size_t)(slots * slot_bytes) > c->cap_ws) {
+		size_t free_b = 0, total_b = 0;
+		HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+		const int64_t budget = (int64_t)((double)(free_b + c->cap_ws) * 0.85);
+		if (slots * slot_bytes > budget) slots = budget / slot_bytes / wpb * wpb;
+		if (slots < wpb) return fail(c, "td_batch_upload: workspace of %lld bytes per wave does not fit in HBM", (long long)slot_bytes);
+		if ((size_t)(slots * slot_bytes) > c->cap_ws) {
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			if (ensure(c, &c->d_ws, &c->cap_ws, (size_t)(slots * slot_bytes)) != TD_OK) return TD_FAIL;
+		}
+	}
+	s.n_wave_slots = (int32_t)slots;
+	s.ws_slot_bytes = slot_bytes;
 	return TD_OK;
 }
 
-extern "C" int td_batch_upload(td_ctx* c, const uint8_t* codes, const int64_t* offs, int64_t n)
+// Reads -> device, sorted and packed.  Copies go on `up` (the compute stream itself for the synchronous calls); the
+// kernels on the compute stream wait for them through ev_up.
+static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, const int64_t* offs, int64_t n, hipStream_t up)
 {
-	return upload_common(c, codes, nullptr, offs, n);
+	s.staged = false; s.ran = false; s.finished = false;
+	s.n_reads = 0; s.n_tiles = 0;
+	if (!c->have_model) return fail(c, "td_batch_upload: no model uploaded");
+	if ((!bases && n > 0 && offs && offs[n] > offs[0]) || !offs || n < 0) return fail(c, "td_batch_upload: bad arguments");
+	if (n > 0x7fffffffLL - TD_WAVE) return fail(c, "td_batch_upload: %lld reads in one batch", (long long)n);
+	HIPCHK(c, hipSetDevice(c->device));
+	if (slot_events(c, s) != TD_OK) return TD_FAIL;
+	if (offs[0] != 0) return fail(c, "td_batch_upload: offs[0] must be 0");
+	// offsets: one pass that copies them into pinned memory and finds the longest / shortest read
+	if (ensure_pinned(c, &s.h_offs, &s.cap_h_offs, (size_t)(n + 1) * 8) != TD_OK) return TD_FAIL;
+	int lmax = 1, lmin = 0x7fffffff;
+	int64_t bad = -1;
+	s.h_offs[0] = 0;
+	for (int64_t i = 0; i < n; i++) {
+		const int64_t l = offs[i + 1] - offs[i];
+		s.h_offs[i + 1] = offs[i + 1];
+		if (l < 0 || l > 100000) { bad = i; break; }
+		if (l > lmax) lmax = (int)l;
+		if (l < lmin) lmin = (int)l;
+	}
+	if (bad >= 0) return fail(c, "td_batch_upload: read %lld has length %lld", (long long)bad, (long long)(offs[bad + 1] - offs[bad]));
+	const int64_t n_bases = n > 0 ? offs[n] : 0;
+	const int64_t n_tiles = (n + TD_WAVE - 1) / TD_WAVE;
+	const int nw2 = (lmax + 15) / 16, nw1 = (lmax + 31) / 32;
+	const bool sorted = n > 0 && lmin != lmax;
+
+	// device buffers
+	const size_t n_packed = (size_t)(n_tiles * (int64_t)(nw2 + nw1) * TD_WAVE), n_lanes = (size_t)(n_tiles * TD_WAVE);
+	const OutLayout ol = out_layout(n_tiles, lmax, nw1);
+	if (ensure(c, &s.d_raw, &s.cap_raw, (size_t)n_bases) != TD_OK || ensure(c, &s.d_offs, &s.cap_offs, (size_t)(n + 1) * 8) != TD_OK ||
+	    ensure(c, &s.d_packed, &s.cap_packed, n_packed * 4) != TD_OK || ensure(c, &s.d_lens, &s.cap_lens, n_lanes * 4) != TD_OK ||
+	    ensure(c, &s.d_art_left, &s.cap_art_left, n_lanes) != TD_OK || ensure(c, &s.d_out, &s.cap_out, (size_t)ol.total) != TD_OK)
+		return TD_FAIL;
+	size_t sort_tmp = 0;
+	if (sorted) {
+		sort_tmp = td_stage_sort_temp_bytes(n, lmax);
+		if (ensure(c, &s.d_read_at, &s.cap_read_at, (size_t)n * 4) != TD_OK || ensure(c, &s.d_keys, &s.cap_keys, (size_t)n * 8) != TD_OK ||
+		    ensure(c, &s.d_vals, &s.cap_vals, (size_t)n * 4) != TD_OK || ensure(c, &s.d_sort_tmp, &s.cap_sort_tmp, sort_tmp) != TD_OK)
+			return TD_FAIL;
+	}
+	s.lmax = lmax; s.nw2 = nw2; s.nw1 = nw1; s.n_tiles = (int32_t)n_tiles;
+	if (ensure_workspace(c, s) != TD_OK) { s.n_tiles = 0; return TD_FAIL; }
+	s.n_tiles = 0;
+
+	// host -> device: page-locked caller memory goes straight to the DMA engine, anything else through pinned staging
+	const void* src = bases;
+	if (n_bases > 0 && !is_pinned(bases)) {
+		if (ensure_pinned(c, &s.h_raw, &s.cap_h_raw, (size_t)n_bases) != TD_OK) return TD_FAIL;
+		parallel_copy(s.h_raw, bases, (size_t)n_bases);
+		src = s.h_raw;
+	}
+	HIPCHK(c, hipMemcpyAsync(s.d_offs, s.h_offs, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, up));
+	if (n_bases > 0) HIPCHK(c, hipMemcpyAsync(s.d_raw, src, (size_t)n_bases, hipMemcpyHostToDevice, up));
+	if (up != c->stream) {
+		HIPCHK(c, hipEventRecord(s.ev_up, up));
+		HIPCHK(c, hipStreamWaitEvent(c->stream, s.ev_up, 0));
+	}
+	if (sorted)
+		HIPCHK(c, td_stage_sort(s.d_offs, n, lmax, s.d_read_at, s.d_keys, s.d_keys + n, s.d_vals, s.d_sort_tmp, sort_tmp, c->stream));
+	TdStageBatch& b = s.sb;
+	b = TdStageBatch{};
+	b.raw = s.d_raw; b.offs = s.d_offs; b.n_reads = n; b.is_ascii = is_ascii;
+	b.n_tiles = (int32_t)n_tiles; b.lmax = lmax; b.nw2 = nw2; b.nw1 = nw1;
+	b.read_at = sorted ? s.d_read_at : nullptr;
+	b.packed = s.d_packed; b.lens = s.d_lens; b.art_left = s.d_art_left;
+	b.out_soa = s.d_out; b.soa_stride = ol.soa_stride;
+	b.keep = (const uint32_t*)(s.d_out + ol.keep); b.labels = (const int8_t*)(s.d_out + ol.labels);
+	HIPCHK(c, td_stage_pack(b, c->stream));
+
+	s.n_reads = n; s.n_bases = n_bases; s.n_tiles = (int32_t)n_tiles; s.is_ascii = is_ascii; s.sorted = sorted;
+	s.staged = true;
+	return TD_OK;
 }
 
-extern "C" int td_batch_upload_ascii(td_ctx* c, const char* bases, const int64_t* offs, int64_t n)
+// the decode kernel over a staged slot
+static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 {
-	return upload_common(c, nullptr, bases, offs, n);
-}
-
-extern "C" int td_run(td_ctx* c, int mode)
-{
-	if (!c) return TD_FAIL;
 	if (!c->have_model) return fail(c, "td_run: no model uploaded");
 	if (mode != TD_MODE_GET_LABEL && mode != TD_MODE_GET_PROB && mode != TD_MODE_ARCH_COMP) return fail(c, "td_run: unsupported mode %d", mode);
+	if (!s.staged) return fail(c, "td_run: no batch resident (td_batch_upload failed or was not called)");
 	HIPCHK(c, hipSetDevice(c->device));
-	if (c->n_tiles == 0) { c->ran = true; c->last_ms = 0.0f; return TD_OK; }
-	const OutLayout ol = out_layout(c->n_tiles, c->lmax, c->nw1);
+	s.mode = mode; s.finished = false;
+	if (s.n_tiles == 0) { s.ran = true; s.last_ms = 0.0f; return TD_OK; }
+	const OutLayout ol = out_layout(s.n_tiles, s.lmax, s.nw1);
 	TdKernelArgs ka{};
 	ka.hdr = c->d_hdr; ka.cols = c->d_cols; ka.hinfo = c->d_hinfo;
 	ka.pred_off = c->d_pred_off; ka.pred_idx = c->d_pred_idx; ka.logsum = c->d_logsum;
-	ka.packed = c->d_packed; ka.lens = c->d_lens;
-	ka.n_tiles = c->n_tiles; ka.n_slots = c->n_slots; ka.lmax = c->lmax; ka.nw2 = c->nw2; ka.nw1 = c->nw1;
+	ka.packed = s.d_packed; ka.lens = s.d_lens;
+	ka.n_tiles = s.n_tiles; ka.n_slots = s.n_wave_slots; ka.lmax = s.lmax; ka.nw2 = s.nw2; ka.nw1 = s.nw1;
 	ka.mode = mode; ka.threshold = c->threshold; ka.minlen = c->minlen; ka.dust = c->dust; ka.want_labels = 1;
-	ka.out_f = (float*)(c->d_out + ol.f); ka.out_b = (float*)(c->d_out + ol.b); ka.out_r = (float*)(c->d_out + ol.r);
-	ka.out_bar = (float*)(c->d_out + ol.bar); ka.out_q = (float*)(c->d_out + ol.q);
-	ka.out_type = (int32_t*)(c->d_out + ol.type); ka.out_barcode = (int32_t*)(c->d_out + ol.barcode);
-	ka.out_finger = (int32_t*)(c->d_out + ol.finger);
-	ka.out_keep = (uint32_t*)(c->d_out + ol.keep); ka.out_labels = (int8_t*)(c->d_out + ol.labels);
+	float* soa = (float*)s.d_out;
+	const int64_t st = ol.soa_stride / 4;
+	ka.out_f = soa; ka.out_b = soa + st; ka.out_r = soa + 2 * st; ka.out_bar = soa + 3 * st; ka.out_q = soa + 4 * st;
+	ka.out_type = (int32_t*)(soa + 5 * st); ka.out_barcode = (int32_t*)(soa + 6 * st); ka.out_finger = (int32_t*)(soa + 7 * st);
+	ka.out_keep = (uint32_t*)(s.d_out + ol.keep); ka.out_labels = (int8_t*)(s.d_out + ol.labels);
 	ka.counters = c->d_counters;
-	ka.ws = c->d_ws; ka.lay = c->lay;
+	ka.ws = c->d_ws; ka.lay = s.lay;
 	if (c->art_n > 0 && mode == TD_MODE_GET_LABEL) {
-		// match_to_reference takes the reads of each thread range [t*interval, ...) in fours and gives the
-		// (range length mod 4) left-over reads to another routine (barcode_hmm.c:2495-2575, ranges :1911-1922)
-		const int64_t n = c->n_reads, T = c->art_threads, interval = n / T;
-		std::vector<uint8_t> left((size_t)c->n_tiles * TD_WAVE, 0);
-		for (int64_t t = 0; t < T; t++) {
-			const int64_t start = t * interval, end = (t == T - 1) ? n : (t + 1) * interval;
-			for (int64_t i = start + (end - start) / 4 * 4; i < end; i++) left[(size_t)c->pos_of[(size_t)i]] = 1;
-		}
-		if (ensure(c, &c->d_art_left, &c->cap_art_left, left.size()) != TD_OK) return TD_FAIL;
-		HIPCHK(c, hipMemcpyAsync(c->d_art_left, left.data(), left.size(), hipMemcpyHostToDevice, c->stream));
-		HIPCHK(c, hipStreamSynchronize(c->stream));   // `left` goes out of scope
-		ka.art_text = c->d_art_text; ka.art_index = c->d_art_index; ka.art_left = c->d_art_left;
+		s.sb.art_threads = c->art_threads;
+		HIPCHK(c, td_stage_art_left(s.sb, c->stream));
+		ka.art_text = c->d_art_text; ka.art_index = c->d_art_index; ka.art_left = s.d_art_left;
 		ka.art_n = c->art_n; ka.art_fe = c->art_fe;
 	}
-	HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+	HIPCHK(c, hipEventRecord(s.ev_k0, c->stream));
 	if (c->spec_ready) {
 		TdSpecArgs sa{};
 		sa.logsum = ka.logsum; sa.packed = ka.packed; sa.lens = ka.lens;
@@ -631,19 +727,109 @@ extern "C" int td_run(td_ctx* c, int mode)
 		sa.out_type = ka.out_type; sa.out_barcode = ka.out_barcode; sa.out_finger = ka.out_finger;
 		sa.out_keep = ka.out_keep; sa.out_labels = ka.out_labels; sa.counters = ka.counters;
 		sa.art_text = ka.art_text; sa.art_index = ka.art_index; sa.art_left = ka.art_left; sa.art_n = ka.art_n; sa.art_fe = ka.art_fe;
-		sa.ws = ka.ws; sa.lay = c->slay;
+		sa.ws = ka.ws; sa.lay = s.slay;
 		size_t sz = sizeof sa;
 		void* cfg[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &sa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END };
 		const int wpb = c->spec_block / TD_WAVE;
-		const unsigned blocks = (unsigned)((c->n_slots + wpb - 1) / wpb);
+		const unsigned blocks = (unsigned)((s.n_wave_slots + wpb - 1) / wpb);
 		HIPCHK(c, hipModuleLaunchKernel(c->spec_fn, blocks, 1, 1, (unsigned)c->spec_block, 1, 1, 0, c->stream, nullptr, cfg));
 	} else {
 		HIPCHK(c, td_launch_decode(&ka, c->stream));
 	}
-	HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-	c->ran = true;
-	c->last_ms = -1.0f;
+	HIPCHK(c, hipEventRecord(s.ev_k1, c->stream));
+	s.ran = true;
+	s.last_ms = -1.0f;
+	c->last_slot = (int)(&s - c->slots);
 	return TD_OK;
+}
+
+// Results into the caller's order on the device, then device -> host on `down`.  A page-locked destination is written by
+// the DMA engine directly; anything else is reached through pinned staging and copied out by slot_fetch_end.
+static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* labels, uint8_t* seq_out, hipStream_t down)
+{
+	if (!s.ran) return fail(c, "td_batch_download: td_run has not been called on this batch");
+	s.u_res = res; s.u_labels = labels; s.u_seq = seq_out;
+	s.res_direct = s.lab_direct = s.seq_direct = false;
+	const int64_t n = s.n_reads;
+	if (n == 0) return TD_OK;
+	const size_t res_bytes = (size_t)n * sizeof(td_read_result), seq_bytes = (size_t)s.n_bases, lab_bytes = (size_t)(s.n_bases + n);
+	if (res && ensure(c, &s.d_res, &s.cap_res, res_bytes) != TD_OK) return TD_FAIL;
+	if (seq_out && ensure(c, &s.d_seq, &s.cap_seq, seq_bytes) != TD_OK) return TD_FAIL;
+	if (labels && ensure(c, &s.d_lab, &s.cap_lab, lab_bytes) != TD_OK) return TD_FAIL;
+	s.sb.res = res ? s.d_res : nullptr;
+	s.sb.seq_out = seq_out ? s.d_seq : nullptr;
+	s.sb.labels_out = labels ? s.d_lab : nullptr;
+	HIPCHK(c, td_stage_finish(s.sb, c->stream));
+	if (down != c->stream) {
+		HIPCHK(c, hipEventRecord(s.ev_done, c->stream));
+		HIPCHK(c, hipStreamWaitEvent(down, s.ev_done, 0));
+	}
+	if (res) {
+		s.res_direct = is_pinned(res);
+		void* dst = res;
+		if (!s.res_direct) { if (ensure_pinned(c, &s.h_res, &s.cap_h_res, res_bytes) != TD_OK) return TD_FAIL; dst = s.h_res; }
+		HIPCHK(c, hipMemcpyAsync(dst, s.d_res, res_bytes, hipMemcpyDeviceToHost, down));
+	}
+	if (seq_out && seq_bytes) {
+		s.seq_direct = is_pinned(seq_out);
+		void* dst = seq_out;
+		if (!s.seq_direct) { if (ensure_pinned(c, &s.h_seq, &s.cap_h_seq, seq_bytes) != TD_OK) return TD_FAIL; dst = s.h_seq; }
+		HIPCHK(c, hipMemcpyAsync(dst, s.d_seq, seq_bytes, hipMemcpyDeviceToHost, down));
+	}
+	if (labels) {
+		s.lab_direct = is_pinned(labels);
+		void* dst = labels;
+		if (!s.lab_direct) { if (ensure_pinned(c, &s.h_lab, &s.cap_h_lab, lab_bytes) != TD_OK) return TD_FAIL; dst = s.h_lab; }
+		HIPCHK(c, hipMemcpyAsync(dst, s.d_lab, lab_bytes, hipMemcpyDeviceToHost, down));
+	}
+	HIPCHK(c, hipEventRecord(s.ev_down, down));
+	s.finished = true;
+	return TD_OK;
+}
+
+static int slot_fetch_end(td_ctx* c, TdSlot& s)
+{
+	if (s.n_reads == 0 || !s.finished) return TD_OK;
+	HIPCHK(c, hipEventSynchronize(s.ev_down));
+	const int64_t n = s.n_reads;
+	if (s.u_res && !s.res_direct) parallel_copy(s.u_res, s.h_res, (size_t)n * sizeof(td_read_result));
+	if (s.u_seq && !s.seq_direct && s.n_bases) parallel_copy(s.u_seq, s.h_seq, (size_t)s.n_bases);
+	if (s.u_labels && !s.lab_direct) parallel_copy(s.u_labels, s.h_lab, (size_t)(s.n_bases + n));
+	return TD_OK;
+}
+
+static bool tickets_outstanding(const td_ctx* c)
+{
+	for (int k = 0; k < TD_MAX_PIPELINE; k++) if (c->slots[k].ticket) return true;
+	return false;
+}
+
+static int upload_common(td_ctx* c, const void* bases, int is_ascii, const int64_t* offs, int64_t n)
+{
+	if (!c) return TD_FAIL;
+	if (tickets_outstanding(c)) return fail(c, "td_batch_upload: td_submit tickets are outstanding (td_wait them first)");
+	TdSlot& s = c->slots[0];
+	if (slot_stage(c, s, bases, is_ascii, offs, n, c->stream) != TD_OK) return TD_FAIL;
+	HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller may reuse its buffers
+	c->last_slot = 0;
+	return TD_OK;
+}
+
+extern "C" int td_batch_upload(td_ctx* c, const uint8_t* codes, const int64_t* offs, int64_t n)
+{
+	return upload_common(c, codes, 0, offs, n);
+}
+
+extern "C" int td_batch_upload_ascii(td_ctx* c, const char* bases, const int64_t* offs, int64_t n)
+{
+	return upload_common(c, bases, 1, offs, n);
+}
+
+extern "C" int td_run(td_ctx* c, int mode)
+{
+	if (!c) return TD_FAIL;
+	if (!c->have_model) return fail(c, "td_run: no model uploaded");
+	return slot_decode(c, c->slots[0], mode);
 }
 
 extern "C" int td_sync(td_ctx* c)
@@ -654,80 +840,91 @@ extern "C" int td_sync(td_ctx* c)
 	return TD_OK;
 }
 
+extern "C" int td_batch_download(td_ctx* c, td_read_result* res, int8_t* labels, uint8_t* seq_out)
+{
+	if (!c) return TD_FAIL;
+	TdSlot& s = c->slots[0];
+	HIPCHK(c, hipSetDevice(c->device));
+	if (slot_fetch_begin(c, s, res, labels, seq_out, c->stream) != TD_OK) return TD_FAIL;
+	return slot_fetch_end(c, s);
+}
+
+// ---- pipelined batches ----
+extern "C" int td_submit(td_ctx* c, const void* bases, int32_t is_ascii, const int64_t* offs, int64_t n_reads, int mode,
+                         td_read_result* res, int8_t* labels, uint8_t* seq_out, int64_t* ticket)
+{
+	if (!c || !ticket) return fail(c, "td_submit: NULL argument");
+	*ticket = 0;
+	HIPCHK(c, hipSetDevice(c->device));
+	if (!c->s_up) {
+		HIPCHK(c, hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking));
+		HIPCHK(c, hipStreamCreateWithFlags(&c->s_down, hipStreamNonBlocking));
+	}
+	int k = -1;
+	for (int j = 0; j < c->pipeline_depth; j++) {   // the slot after the one used last, if free
+		const int cand = (c->next_slot + j) % c->pipeline_depth;
+		if (!c->slots[cand].ticket) { k = cand; break; }
+	}
+	if (k < 0) return fail(c, "td_submit: all %d pipeline slots hold batches that have not been waited for", c->pipeline_depth);
+	TdSlot& s = c->slots[k];
+	if (slot_stage(c, s, bases, is_ascii != 0, offs, n_reads, c->s_up) != TD_OK) return TD_FAIL;
+	if (slot_decode(c, s, mode) != TD_OK) return TD_FAIL;
+	if (slot_fetch_begin(c, s, res, labels, seq_out, c->s_down) != TD_OK) return TD_FAIL;
+	s.ticket = ++c->ticket_counter;
+	c->next_slot = (k + 1) % c->pipeline_depth;
+	*ticket = s.ticket;
+	return TD_OK;
+}
+
+extern "C" int td_wait(td_ctx* c, int64_t ticket)
+{
+	if (!c) return TD_FAIL;
+	HIPCHK(c, hipSetDevice(c->device));
+	for (int k = 0; k < TD_MAX_PIPELINE; k++) {
+		TdSlot& s = c->slots[k];
+		if (ticket != 0 && s.ticket == ticket) {
+			const int rc = slot_fetch_end(c, s);
+			s.ticket = 0;
+			c->last_slot = k;   // td_last_kernel_ms / td_batch_info now describe this batch
+			return rc;
+		}
+	}
+	return fail(c, "td_wait: no batch with ticket %lld is in flight", (long long)ticket);
+}
+
+extern "C" void* td_host_alloc(size_t bytes)
+{
+	void* p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	return p;
+}
+
+extern "C" void td_host_free(void* p)
+{
+	if (p) (void)hipHostFree(p);
+}
+
 extern "C" int td_last_kernel_ms(td_ctx* c, float* ms)
 {
 	if (!c || !ms) return TD_FAIL;
-	if (!c->ran) return fail(c, "td_last_kernel_ms: nothing has run");
+	TdSlot& s = c->slots[c->last_slot];
+	if (!s.ran) return fail(c, "td_last_kernel_ms: nothing has run");
 	HIPCHK(c, hipSetDevice(c->device));
-	if (c->last_ms < 0.0f && c->n_tiles > 0) {
-		HIPCHK(c, hipEventSynchronize(c->ev1));
-		HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+	if (s.last_ms < 0.0f && s.n_tiles > 0) {
+		HIPCHK(c, hipEventSynchronize(s.ev_k1));
+		HIPCHK(c, hipEventElapsedTime(&s.last_ms, s.ev_k0, s.ev_k1));
 	}
-	*ms = c->last_ms;
+	*ms = s.last_ms;
 	return TD_OK;
 }
 
 extern "C" int td_batch_info(td_ctx* c, int64_t* n_reads, int64_t* workspace_bytes, int32_t* wave_slots)
 {
 	if (!c) return TD_FAIL;
-	if (n_reads) *n_reads = c->n_reads;
-	if (workspace_bytes) *workspace_bytes = (int64_t)c->n_slots * (c->spec_ready ? c->slay.slot_bytes : c->lay.slot_bytes);
-	if (wave_slots) *wave_slots = c->n_slots;
-	return TD_OK;
-}
-
-extern "C" int td_batch_download(td_ctx* c, td_read_result* res, int8_t* labels, uint8_t* seq_out)
-{
-	if (!c) return TD_FAIL;
-	if (!c->ran) return fail(c, "td_batch_download: td_run has not been called on this batch");
-	HIPCHK(c, hipSetDevice(c->device));
-	HIPCHK(c, hipStreamSynchronize(c->stream));
-	const int64_t n = c->n_reads;
-	if (n == 0) return TD_OK;
-	const OutLayout ol = out_layout(c->n_tiles, c->lmax, c->nw1);
-	// one pinned staging buffer with the device layout; only the regions asked for cross the link
-	if (ensure_pinned(c, &c->h_out, &c->cap_h_out, (size_t)ol.total) != TD_OK) return TD_FAIL;
-	const size_t keep_bytes = (size_t)c->n_tiles * c->nw1 * TD_WAVE * 4;
-	const size_t label_bytes = (size_t)c->n_tiles * (c->lmax + 1) * TD_WAVE;
-	if (res) HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, (size_t)ol.keep, hipMemcpyDeviceToHost, c->stream));
-	if (seq_out) HIPCHK(c, hipMemcpyAsync(c->h_out + ol.keep, c->d_out + ol.keep, keep_bytes, hipMemcpyDeviceToHost, c->stream));
-	if (labels) HIPCHK(c, hipMemcpyAsync(c->h_out + ol.labels, c->d_out + ol.labels, label_bytes, hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(c, hipStreamSynchronize(c->stream));
-	const uint8_t* h = c->h_out;
-	const float* f = (const float*)(h + ol.f); const float* b = (const float*)(h + ol.b);
-	const float* r = (const float*)(h + ol.r); const float* bar = (const float*)(h + ol.bar);
-	const float* q = (const float*)(h + ol.q); const int32_t* ty = (const int32_t*)(h + ol.type);
-	const int32_t* bc = (const int32_t*)(h + ol.barcode); const int32_t* fg = (const int32_t*)(h + ol.finger);
-	const int8_t* hl = (const int8_t*)(h + ol.labels);
-	const uint32_t* hk = (const uint32_t*)(h + ol.keep);
-	// un-permute (device order is length-sorted) and un-interleave ([..][64 lanes] -> per read), all three in one pass
-	parallel_ranges(n, [&](int64_t lo, int64_t hi) {
-		for (int64_t i = lo; i < hi; i++) {
-			const int64_t k = c->pos_of[(size_t)i];
-			const int64_t tile = k / TD_WAVE; const int lane = (int)(k % TD_WAVE);
-			const int l = (int)(c->offs[i + 1] - c->offs[i]);
-			if (res) {
-				res[i].f_score = f[k]; res[i].b_score = b[k]; res[i].r_score = r[k]; res[i].bar_prob = bar[k];
-				res[i].mapq = q[k]; res[i].read_type = ty[k]; res[i].barcode = bc[k]; res[i].fingerprint = fg[k];
-			}
-			if (labels) {
-				const int8_t* src = hl + tile * (int64_t)(c->lmax + 1) * TD_WAVE + lane;
-				int8_t* dst = labels + c->offs[i] + i;
-				for (int kk = 0; kk <= l; kk++) dst[kk] = src[kk * TD_WAVE];
-			}
-			if (seq_out) {
-				const uint32_t* kw = hk + tile * (int64_t)c->nw1 * TD_WAVE + lane;
-				const uint8_t* cd = c->codes_host.data() + c->offs[i];
-				uint8_t* dst = seq_out + c->offs[i];
-				for (int k0 = 0; k0 < l; k0 += 32) {
-					const uint32_t w = kw[(k0 >> 5) * TD_WAVE];
-					const int e = l - k0 < 32 ? l - k0 : 32;
-					if (w == 0xFFFFFFFFu) memcpy(dst + k0, cd + k0, (size_t)e);      // whole word kept (unextracted reads)
-					else for (int kk = 0; kk < e; kk++) dst[k0 + kk] = ((w >> kk) & 1u) ? cd[k0 + kk] : 65; // spacer byte, barcode_hmm.c:3348
-				}
-			}
-		}
-	});
+	const TdSlot& s = c->slots[c->last_slot];
+	if (n_reads) *n_reads = s.n_reads;
+	if (workspace_bytes) *workspace_bytes = (int64_t)s.n_wave_slots * s.ws_slot_bytes;
+	if (wave_slots) *wave_slots = s.n_wave_slots;
 	return TD_OK;
 }
 

@@ -20,6 +20,7 @@ ABI_SYMBOLS = [
     "td_ctx_create", "td_ctx_destroy", "td_last_error", "td_logsum_table", "td_model_upload", "td_set_params",
     "td_batch_upload", "td_batch_upload_ascii", "td_run", "td_sync", "td_batch_download", "td_counts_reset",
     "td_counts_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_batch_info", "td_set_option", "td_get_option", "td_set_artifacts", "td_spec_source",
+    "td_submit", "td_wait", "td_host_alloc", "td_host_free",
 ]
 IO_ABI_SYMBOLS = ["td_reads_parse", "td_reads_free", "td_writer_open", "td_writer_write", "td_writer_close",
                   "td_fasta_parse", "td_fasta_free"]
@@ -95,6 +96,13 @@ def load_library():
     lib.td_run.argtypes = [C.c_void_p, C.c_int]
     lib.td_sync.argtypes = [C.c_void_p]
     lib.td_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.td_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.POINTER(C.c_int64)]
+    lib.td_wait.argtypes = [C.c_void_p, C.c_int64]
+    lib.td_host_alloc.argtypes = [C.c_size_t]
+    lib.td_host_alloc.restype = C.c_void_p
+    lib.td_host_free.argtypes = [C.c_void_p]
+    lib.td_host_free.restype = None
     lib.td_counts_reset.argtypes = [C.c_void_p]
     lib.td_counts_get.argtypes = [C.c_void_p, C.c_void_p]
     lib.td_counts_device_ptr.argtypes = [C.c_void_p]
@@ -448,6 +456,19 @@ class TagdustHip:
                                              sq.ctypes.data if seq else None))
         return res, lab, sq
 
+    def submit(self, bases, offs, mode=MODE_GET_LABEL, res=None, labels=None, seq_out=None, ascii=False):
+        """td_submit: numpy arrays in (kept alive by the caller until wait()), result arrays named now; returns the ticket."""
+        n = len(offs) - 1
+        t = C.c_int64(0)
+        self._chk(self.lib.td_submit(self.h, bases.ctypes.data, 1 if ascii else 0, offs.ctypes.data, n, int(mode),
+                                     res.ctypes.data if res is not None else None,
+                                     labels.ctypes.data if labels is not None else None,
+                                     seq_out.ctypes.data if seq_out is not None else None, C.byref(t)))
+        return int(t.value)
+
+    def wait(self, ticket):
+        self._chk(self.lib.td_wait(self.h, int(ticket)))
+
     def counts_reset(self):
         self._chk(self.lib.td_counts_reset(self.h))
 
@@ -465,3 +486,29 @@ class TagdustHip:
         n, w, s = C.c_int64(), C.c_int64(), C.c_int32()
         self._chk(self.lib.td_batch_info(self.h, C.byref(n), C.byref(w), C.byref(s)))
         return int(n.value), int(w.value), int(s.value)
+
+
+class PinnedArray:
+    """A numpy view of page-locked host memory from td_host_alloc (batch inputs / outputs the DMA engines use directly)."""
+
+    def __init__(self, shape, dtype):
+        self.lib = load_library()
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape))
+        self.ptr = self.lib.td_host_alloc(max(n * dt.itemsize, 1))
+        if not self.ptr:
+            raise TdError("td_host_alloc(%d bytes) failed" % (n * dt.itemsize))
+        buf = (C.c_uint8 * (n * dt.itemsize)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self.lib.td_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,139 @@
+"""Pipelined batches (td_submit / td_wait): several batches in flight, copies on their own streams, device-side ingest and
+egress.  Results must equal the reference fixtures and the synchronous path bit for bit, for pageable and page-locked
+buffers, ragged and uniform batches, base codes and FASTQ text."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _ctx(g, specialize=1, depth=2):
+    from tagdust_amd import TagdustHip
+    c = TagdustHip(0)
+    c.set_option("specialize", specialize)
+    c.set_option("pipeline_depth", depth)
+    c.upload_model(g)
+    c.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+    return c
+
+
+def _check_against_fixture(g, res, labels, seq, idx=None):
+    sel = (lambda a: a) if idx is None else (lambda a: a[idx])
+    for k in ("b_score", "f_score", "r_score"):
+        assert np.array_equal(_bits(res[k]), _bits(sel(g[k]))), k
+    assert np.array_equal(_bits(res["bar_prob"]), _bits(sel(g["bar_prob"]).astype(np.float32)))
+    assert np.allclose(res["mapq"], sel(g["mapq"]), rtol=0, atol=1e-4)
+    for k in ("read_type", "barcode", "fingerprint"):
+        assert np.array_equal(res[k], sel(g[k])), k
+
+
+@pytest.mark.parametrize("specialize", [1, 0], ids=["specialised", "generic"])
+@pytest.mark.parametrize("name", ["c3_b6_s_r_p", "c2_indel_varlen", "umi_f_s_r"])
+def test_submit_wait_equals_fixture(name, specialize):
+    from tagdust_amd import RESULT_DTYPE
+    g = load_golden(name)
+    c = _ctx(g, specialize)
+    try:
+        n = int(g["n_reads"])
+        offs = np.ascontiguousarray(g["offs"], np.int64)
+        seq = np.ascontiguousarray(g["seq"], np.uint8)
+        res = np.zeros(n, RESULT_DTYPE)
+        lab = np.zeros(int(offs[-1]) + n, np.int8)
+        sq = np.zeros(int(offs[-1]), np.uint8)
+        t = c.submit(seq, offs, res=res, labels=lab, seq_out=sq)
+        c.wait(t)
+        _check_against_fixture(g, res, lab, sq)
+        assert np.array_equal(lab, g["labels"]) and np.array_equal(sq, g["seq_after"])
+    finally:
+        c.close()
+
+
+def test_many_batches_in_flight_match_synchronous_path():
+    """Eight batches of different sizes and length mixes through a depth-3 pipeline, pageable and page-locked buffers
+    alternating, FASTQ text and base codes alternating; every batch equals what the synchronous calls give for it."""
+    from tagdust_amd import RESULT_DTYPE, TdError
+    from tagdust_amd.lib import PinnedArray
+    g = load_golden("c2_b4_r")
+    rng = np.random.RandomState(11)
+    src_offs = g["offs"]
+    batches = []
+    for b in range(8):
+        n = int(rng.choice([1, 63, 64, 65, 500, 3000, 20000]))
+        uniform = b % 3 == 0
+        lens = np.full(n, 100) if uniform else rng.randint(20, 101, n)
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        codes = rng.randint(0, 4, int(offs[-1])).astype(np.uint8)
+        codes[rng.random_sample(len(codes)) < 0.004] = 4
+        for i in range(0, n, 2):
+            k = i % int(g["n_reads"])
+            s_ = g["seq"][src_offs[k]:src_offs[k + 1]][:lens[i]]
+            codes[offs[i]:offs[i] + len(s_)] = s_
+        batches.append((codes, offs))
+    c = _ctx(g, 1, depth=3)
+    try:
+        # synchronous reference results
+        want = []
+        for codes, offs in batches:
+            c.upload_batch(codes, offs)
+            c.run()
+            want.append(c.download())
+        c.counts_reset()
+        keep, tickets, got = [], [], []
+        for b, (codes, offs) in enumerate(batches):
+            n = len(offs) - 1
+            ascii_ = b % 2 == 1
+            data = np.frombuffer(b"ACGTN", np.uint8)[codes] if ascii_ else codes
+            if b % 4 < 2:      # page-locked in and out
+                pin = [PinnedArray(data.shape, np.uint8), PinnedArray((n,), RESULT_DTYPE), PinnedArray((int(offs[-1]) + n,), np.int8),
+                       PinnedArray((int(offs[-1]),), np.uint8)]
+                pin[0].array[:] = data
+                keep.append(pin)
+                data, res, lab, sq = (p.array for p in pin)
+            else:
+                res, lab, sq = np.zeros(n, RESULT_DTYPE), np.zeros(int(offs[-1]) + n, np.int8), np.zeros(int(offs[-1]), np.uint8)
+            if len(tickets) == 3:          # the pipeline is full: a fourth submit must be refused, not block or overwrite
+                with pytest.raises(TdError, match="pipeline slots"):
+                    c.submit(data, offs, res=res, labels=lab, seq_out=sq, ascii=ascii_)
+                c.wait(tickets.pop(0))
+            tickets.append(c.submit(data, offs, res=res, labels=lab, seq_out=sq, ascii=ascii_))
+            keep.append((data, offs))
+            got.append((res, lab, sq))
+        for t in tickets:
+            c.wait(t)
+        for b, ((res, lab, sq), (wres, wlab, wsq)) in enumerate(zip(got, want)):
+            assert res.tobytes() == wres.tobytes(), b
+            assert np.array_equal(lab, wlab), b
+            assert np.array_equal(sq, wsq), b
+        cnt = c.counts()
+        assert int(cnt[:8].sum()) == sum(len(o) - 1 for _, o in batches)
+        with pytest.raises(TdError, match="no batch with ticket"):
+            c.wait(12345)
+    finally:
+        c.close()
+        for pin in keep:
+            if isinstance(pin, list):
+                for p in pin:
+                    p.free()
+
+
+def test_submit_prob_mode_and_partial_outputs():
+    """TD_MODE_GET_PROB through the pipeline (what threshold calibration uses), records only."""
+    from tagdust_amd import RESULT_DTYPE, MODE_GET_PROB
+    g = load_golden("scen2_p_b_r_p")
+    c = _ctx(g)
+    try:
+        n = int(g["n_reads"])
+        offs = np.ascontiguousarray(g["offs"], np.int64)
+        seq = np.ascontiguousarray(g["seq"], np.uint8)
+        res = np.zeros(n, RESULT_DTYPE)
+        c.wait(c.submit(seq, offs, mode=MODE_GET_PROB, res=res))
+        assert np.array_equal(_bits(res["f_score"]), _bits(g["f_score"]))
+        assert np.allclose(res["mapq"], g["mapq"], rtol=0, atol=1e-4)
+    finally:
+        c.close()
