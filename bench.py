@@ -201,15 +201,22 @@ class _DevCounters:
 def run_pipelined(ctx, host_batches, offs, outs, steps, depth):
     """`steps` host-to-host batches through td_submit / td_wait, `depth` in flight; returns per-batch kernel ms."""
     tickets, k_ms = [], []
+    trace = [] if os.environ.get("TD_BENCH_TRACE") else None
     for k in range(steps):
         o = outs[k % len(outs)]
+        t0 = time.perf_counter()
         tickets.append(ctx.submit(host_batches[k % len(host_batches)], offs, res=o[0], seq_out=o[1]))
+        t1 = time.perf_counter()
         if len(tickets) >= depth:
             ctx.wait(tickets.pop(0))
             k_ms.append(ctx.last_kernel_ms())
+        if trace is not None:
+            trace.append((1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t1)))
     for t in tickets:
         ctx.wait(t)
         k_ms.append(ctx.last_kernel_ms())
+    if trace:
+        sys.stderr.write("submit/wait ms per step: " + " ".join("%.1f/%.1f" % x for x in trace) + "\n")
     return k_ms
 
 

@@ -75,6 +75,14 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise TdError("%s is missing: run `python -m tagdust_amd.build` (or __graft_entry__.build()); "
                       "there is no CPU fallback" % LIB_PATH)
+    if "TD_LIB_PATH" not in os.environ:
+        try:   # a library older than its sources measures / tests the wrong code: say so (the GPU box only has the prebuilt file)
+            from . import build as _b
+            if _b.needs_build():
+                import sys
+                sys.stderr.write("tagdust_amd: %s is older than its sources -- run `python -m tagdust_amd.build`\n" % LIB_PATH)
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     lib.td_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     lib.td_ctx_destroy.argtypes = [C.c_void_p]

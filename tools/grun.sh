@@ -1,0 +1,8 @@
+#!/bin/bash
+# build everything here (hipcc cross-compiles without a GPU), then run the given command on an MI355X box
+# usage: tools/grun.sh [--timeout S] -- '<command>'
+set -e
+cd "$(dirname "$0")/.."
+python -m tagdust_amd.build > /dev/null
+make -s -C oracle libtd_oracle.so
+exec /usr/local/graft/bin/gpurun "$@"
