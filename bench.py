@@ -53,6 +53,13 @@ WORKLOADS = {
 _ACTIVE = dict(WORKLOADS["c3"])
 
 
+def select_workload(name):
+    """Make `name` (c2 / c3 / c5) the workload synth_batch() and load_model() work on."""
+    global READ_LEN
+    _ACTIVE.update(WORKLOADS[name])
+    READ_LEN = _ACTIVE["read_len"]
+
+
 def synth_batch(n, seed, read_len=None, random_frac=0.1, sub=0.02):
     if _ACTIVE["fixture"] != "c3_b6_s_r_p":
         return synth_batch_generic(n, seed, _ACTIVE, random_frac, sub)
@@ -224,9 +231,7 @@ def measure_workload(name, n, steps, warmup, dev_index, specialize=1, depth=2, p
     """One workload on this rank's GPU: model upload, oracle spot-check, warm-up, then the caller times `go()`."""
     from tagdust_amd import TagdustHip, RESULT_DTYPE
     from tagdust_amd.lib import PinnedArray
-    global READ_LEN
-    _ACTIVE.update(WORKLOADS[name])
-    READ_LEN = _ACTIVE["read_len"]
+    select_workload(name)
     model = load_model()
     ctx = TagdustHip(dev_index)
     ctx.set_option("specialize", specialize)
@@ -448,11 +453,10 @@ def main():
                 close2()
             except SystemExit as e:
                 extra[key] = {"error": str(e)}
-        _ACTIVE.update(WORKLOADS[args.workload])
+        select_workload(args.workload)
     if rank == 0:
         out["extra"] = extra
         if args.cpu_sample and world == 1:
-            globals()["READ_LEN"] = WORKLOADS[args.workload]["read_len"]
             out["cpu_baseline"] = cpu_baseline(model, args.cpu_sample, seed=77)
         elif args.cpu_sample:
             out["cpu_baseline"] = None

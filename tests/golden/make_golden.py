@@ -234,6 +234,47 @@ def scenarios(tmp):
         return fq, ["-seed", "42", "-1", "B:" + ",".join(bars), "-2", "F:NNNNNNNN", "-3", "R:N", "-4", "P:" + ADAPTER]
     sc["c5_b96_f_r_p"] = c5
 
+
+    def c5_big():  # config-5 architecture (H = 100) on >= 1000 reads covering every outcome of the label path
+        fq = os.path.join(tmp, "c5big.fq")
+        bars = read_tags(os.path.join(dev, "EDITTAG_6nt_ed_3.txt"), 96)
+        rng = np.random.RandomState(55)
+
+        def dna(n):
+            return "".join("ACGT"[k] for k in rng.randint(0, 4, n))
+        with open(fq, "w") as fh:
+            for i in range(1100):
+                kind = rng.choice(8, p=[0.52, 0.08, 0.08, 0.08, 0.08, 0.08, 0.04, 0.04])
+                L = 150 if rng.random_sample() < 0.7 else int(rng.randint(40, 150))
+                b = bars[rng.randint(96)]
+                umi = dna(8)
+                ad = ADAPTER[:int(rng.randint(0, len(ADAPTER) + 1))]
+                if kind == 1:      # UMI of the wrong length: fingerprint not found
+                    umi = dna(int(rng.choice([5, 6, 7, 9, 10, 11])))
+                elif kind == 2:    # a 6-mer that is no barcode: decoy HMM
+                    b = dna(6)
+                if kind == 3:      # insert shorter than -minlen in front of the whole adapter
+                    s_ = b + umi + dna(int(rng.randint(2, 15))) + ADAPTER
+                elif kind == 4:    # low-complexity insert: DUST
+                    u = dna(int(rng.randint(1, 4)))
+                    s_ = b + umi + (u * 150)[:max(L - 14 - len(ad), 20)] + ad
+                elif kind == 5:    # unrelated sequence
+                    s_ = dna(L)
+                elif kind == 6:    # barcode with two substitutions / an indel
+                    bb = list(b)
+                    bb[rng.randint(6)] = "ACGT"[rng.randint(4)]
+                    bb[rng.randint(6)] = "ACGT"[rng.randint(4)]
+                    if rng.random_sample() < 0.5:
+                        del bb[rng.randint(len(bb))]
+                    s_ = "".join(bb) + umi + dna(max(L - 14 - len(ad), 20)) + ad
+                else:
+                    s_ = mutate(rng, b + umi, 0.02, 0.01) + dna(max(L - 14 - len(ad), 20)) + mutate(rng, ad, 0.02, 0.01)
+                if kind == 7:      # N bases anywhere
+                    s_ = "".join("N" if rng.random_sample() < 0.03 else ch for ch in s_)
+                fh.write("@READ%d;KIND:%d\n%s\n+\n%s\n" % (i, kind, s_, "I" * len(s_)))
+        return fq, ["-seed", "42", "-1", "B:" + ",".join(bars), "-2", "F:NNNNNNNN", "-3", "R:N", "-4", "P:" + ADAPTER]
+    sc["c5_big_b96_f_r_p"] = c5_big
+
     def scen1():  # dev/bar_read_test.sh scenario 1 (first 400 reads + the random tail)
         fq = os.path.join(tmp, "s1.fq")
         arch = simreads(fq, os.path.join(dev, "EDITTAG_6nt_ed_4.txt"),

@@ -343,16 +343,19 @@ def test_long_reads_switch_to_clamped_logsum(monkeypatch):
     assert np.array_equal(seq0, seq1) and np.array_equal(seq0, g["seq_after"])
 
 
-def test_full_size_batch_properties():
-    """BASELINE.json's bench shape at full batch size (2^20 reads of 150 bp, config-3 architecture): the oracle cannot
-    cover a million reads in seconds, so the batch is checked through properties that do not depend on its size --
-    a batch decodes like its permutation, like its halves, and like itself a second time; the device counters add up;
-    and a random sample is bit-identical to the oracle."""
+@pytest.mark.parametrize("workload,n", [("c3", 1 << 20), ("c2", 1 << 20), ("c5", 1 << 19)], ids=["config3", "config2", "config5"])
+def test_full_size_batch_properties(workload, n):
+    """BASELINE.json's shapes at full batch size (2^20 reads; 2^19 for the 100-HMM architecture of configs[4], whose
+    workspace is 42 MiB per wave): the oracle cannot cover a million reads in seconds, so the batch is checked through
+    properties that do not depend on its size -- a batch decodes like its permutation, like its halves, and like itself
+    a second time (through the pipelined calls as well); the device counters add up; and a random sample is bit-identical
+    to the oracle."""
     import bench
     from oracle import pyoracle
-    from tagdust_amd import TagdustHip
+    from tagdust_amd import TagdustHip, RESULT_DTYPE
+    bench.select_workload(workload)
     model = bench.load_model()
-    n, L = 1 << 20, bench.READ_LEN
+    L = bench.READ_LEN
     reads = bench.synth_batch(n, 20240607).reshape(n, L)
     offs = np.arange(n + 1, dtype=np.int64) * L
     c = TagdustHip(0)
@@ -374,11 +377,14 @@ def test_full_size_batch_properties():
             assert cnt[code] == int(((res["read_type"] & 0xFF) == code).sum())
         ok = (res["read_type"] == 0) & (res["barcode"] >= 0)
         assert np.array_equal(cnt[8:], np.bincount(res["barcode"][ok] & 0xFF, minlength=256))
-        assert 0.80 * n < cnt[0] < 0.95 * n                                 # ~90 % of the synthetic reads carry the architecture
-        # idempotence
-        res2, labels2, seq2, _ = decode(reads)
+        assert 0.75 * n < cnt[0] < 0.97 * n                                 # ~90 % of the synthetic reads carry the architecture
+        # idempotence, and the pipelined calls give the same bytes
+        res2 = np.zeros(n, RESULT_DTYPE)
+        labels2 = np.zeros(n * (L + 1), np.int8)
+        seq2 = np.zeros(n * L, np.uint8)
+        c.wait(c.submit(np.ascontiguousarray(reads.reshape(-1)), offs, res=res2, labels=labels2, seq_out=seq2))
         assert res.tobytes() == res2.tobytes() and np.array_equal(labels, labels2) and np.array_equal(seq, seq2)
-        # permutation: the device order is length-sorted and tiles hold 64 neighbours; a read must not care who they are
+        # permutation: tiles hold 64 neighbours; a read must not care who they are
         perm = np.random.default_rng(5).permutation(n)
         resp, labelsp, seqp, cntp = decode(reads[perm])
         assert resp.tobytes() == res[perm].tobytes()
@@ -394,11 +400,13 @@ def test_full_size_batch_properties():
         assert np.array_equal(ca + cb, cnt)
     finally:
         c.close()
+        bench.select_workload("c3")
     # a random sample against the oracle, bit for bit
-    pick = np.sort(np.random.default_rng(6).choice(n, 3000, replace=False))
+    ns = 3000 if workload != "c5" else 2000
+    pick = np.sort(np.random.default_rng(6).choice(n, ns, replace=False))
     om = pyoracle.OracleModel(model)
     ores, olab, oseq = pyoracle.label_batch(om, reads[pick].reshape(-1), offs[:len(pick) + 1], float(model["threshold"]),
-                                            int(model["minlen"]), int(model["dust"]), n_threads=8)
+                                            int(model["minlen"]), int(model["dust"]), n_threads=16)
     for k, ok_ in (("b_score", "b_score"), ("f_score", "f_score"), ("r_score", "r_score"), ("bar_prob", "bar_prob"), ("mapq", "Q")):
         assert np.array_equal(_bits(res[k][pick]), _bits(ores[ok_]))
     for k in ("read_type", "barcode", "fingerprint"):
@@ -525,6 +533,72 @@ def test_random_architectures_against_oracle(ctx, seed):
     for k in ("read_type", "barcode", "fingerprint"):
         assert np.array_equal(res[k], ores[k]), (k, segs)
     assert np.array_equal(seq_after, oseq), segs
+
+
+@pytest.mark.parametrize("nb,linker_first,umi", [(60, False, True), (96, False, True), (96, True, False), (62, True, True), (97, False, False)],
+                         ids=["H64-first", "H100-first", "H100-behind-5p-linker", "H67-behind-5p-linker", "H99-b97-r"])
+def test_many_label_architectures_against_oracle(ctx, nb, linker_first, umi):
+    """Architectures at and near the reference's limit of 100 HMMs (total_prob[100], barcode_hmm.c:4186): the run-time HMM
+    loop, the workspace label DP (:4447-4472 over > 32 labels) and -- with the big segment first -- the in-sweep label sums,
+    and with a 5' linker in front of it the run-wise label DP.  Models from the library's own builder; reads with
+    substitutions, indels, Ns, wrong-length UMIs, non-barcodes, short inserts and unrelated sequences; both kernels equal the
+    oracle bit for bit."""
+    from oracle import pyoracle
+    from tagdust_amd import lib as tdlib
+    rng = np.random.RandomState(4000 + nb + 7 * linker_first)
+
+    def dna(n):
+        return "".join("ACGT"[x] for x in rng.randint(0, 4, n))
+    bars = sorted({dna(6) for _ in range(4 * nb)})[:nb]
+    assert len(bars) == nb
+    five = "ACGTTGCATCGG"
+    three = "AGATCGGAAGAGC"
+    segs = (["P:" + five] if linker_first else []) + ["B:" + ",".join(bars)] + (["F:NNNNNNNN"] if umi else []) + ["R:N"]
+    if nb != 97:
+        segs.append("P:" + three)
+    code = {"A": 0, "C": 1, "G": 2, "T": 3, "N": 4}
+    reads = []
+    for i in range(330):
+        kind = rng.randint(10)
+        b = bars[rng.randint(nb)] if kind != 1 else dna(6)
+        u = dna(8 if kind != 2 else int(rng.choice([6, 7, 9]))) if umi else ""
+        ins = dna(int(rng.randint(20, 70)) if kind != 3 else int(rng.randint(2, 14)))
+        s_ = (five[rng.randint(0, len(five)):] if linker_first else "") + b + u + ins
+        if nb != 97:
+            s_ += three[:rng.randint(0, len(three) + 1)] if kind != 3 else three
+        out = []
+        for ch in s_:
+            v = rng.random_sample()
+            if v < 0.02:
+                out.append("ACGT"[rng.randint(4)])
+            elif v < 0.025:
+                continue
+            elif v < 0.03:
+                out.append(ch); out.append("ACGT"[rng.randint(4)])
+            elif v < 0.033:
+                out.append("N")
+            else:
+                out.append(ch)
+        s_ = "".join(out)
+        if kind == 4:
+            s_ = dna(int(rng.randint(20, 100)))
+        reads.append(np.array([code[ch] for ch in s_], np.uint8))
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    seq = np.concatenate(reads)
+    md, _ = tdlib.build_model(segs, seq, offs, 0.05, 0.1)
+    assert int(md["H"]) == nb + 1 + (1 if umi else 0) + 1 + (1 if nb != 97 else 0) + (1 if linker_first else 0)
+    thr = 1.0
+    md.update(threshold=thr, minlen=16, dust=100)
+    ores, olab, oseq = pyoracle.label_batch(pyoracle.OracleModel(md), seq, offs, thr, 16, 100, 16)
+    assert len(set(ores["read_type"].tolist())) >= 3
+    res, labels, seq_after = _run(ctx, md, seq, offs, threshold=thr)
+    for k in ("b_score", "f_score", "r_score", "bar_prob"):
+        assert np.array_equal(_bits(res[k]), _bits(ores[k])), (k, segs[0][:12])
+    assert np.array_equal(labels, olab)
+    assert np.allclose(res["mapq"], ores["Q"], rtol=0, atol=Q_TOL)
+    for k in ("read_type", "barcode", "fingerprint"):
+        assert np.array_equal(res[k], ores[k]), k
+    assert np.array_equal(seq_after, oseq)
 
 
 @pytest.mark.parametrize("name", ["c2_b4_r", "c3_b6_s_r_p", "scen2_p_b_r_p", "c2_indel_varlen", "b_r_s_r"])
