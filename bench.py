@@ -319,7 +319,7 @@ def main():
     ap.add_argument("--check", type=int, default=2048, help="reads verified against the oracle before timing (0 = skip)")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS), help="development only; the bench line is c3")
     ap.add_argument("--specialize", type=int, default=1, help="0 = generic ahead-of-time kernel")
-    ap.add_argument("--depth", type=int, default=2, help="batches in flight (td_submit pipeline depth)")
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight (td_submit pipeline depth)")
     ap.add_argument("--pinned", type=int, default=0, help="1 = the caller's buffers are page-locked (td_host_alloc): no host copies at all")
     ap.add_argument("--extras", type=int, default=1, help="0 = skip the extra measurements (kernel only, pinned I/O, configs 2 and 5)")
     args = ap.parse_args()

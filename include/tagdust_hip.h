@@ -113,7 +113,7 @@ const float* td_logsum_table(void);
  * model with hiprtc -- a few seconds, once per architecture.  A compile failure is TD_FAIL, not a fallback. */
 int td_model_upload(td_ctx* ctx, const td_model_desc* model);
 /* Options:  "specialize" (set before td_model_upload) 1 = model-specialised kernel (default; env TD_SPECIALIZE),
- * 0 = the generic ahead-of-time kernel that reads the model from HBM;  "pipeline_depth" 1..4 (default 2) = batches
+ * 0 = the generic ahead-of-time kernel that reads the model from HBM;  "pipeline_depth" 1..4 (default 3) = batches
  * td_submit may hold in flight. */
 int td_set_option(td_ctx* ctx, const char* name, int32_t value);
 /* Read a setting back: "specialize", "pipeline_depth", or "spec_lsum_clamped" (1 when the loaded specialised kernel uses the clamped

@@ -53,6 +53,7 @@ struct TdSlot {
 	int64_t ticket = 0;       // td_submit: 0 = free
 	td_read_result* u_res = nullptr; int8_t* u_labels = nullptr; uint8_t* u_seq = nullptr;   // the caller's output buffers
 	bool res_direct = false, lab_direct = false, seq_direct = false;                          // ... are page-locked
+	bool copies_deferred = false;   // td_wait issues the device-to-host copies (pipelined calls)
 	TdStageBatch sb{};
 	TdWsLayout lay{};
 	TdSpecLayout slay{};
@@ -113,6 +114,7 @@ struct td_ctx {
 	std::vector<int8_t> m_seg_type;
 	std::vector<int32_t> m_finger_len;
 	bool spec_oob = false;      // the loaded kernel uses the clamp-free logsum
+	bool spec_oob_unsafe = false; // the clamp-free form failed its self-check once: never again in this context
 	float m_maxabs = 0.0f;      // largest |finite parameter|
 	int spec_block = 256, spec_waves_per_cu = 8;
 
@@ -125,7 +127,7 @@ struct td_ctx {
 	int32_t art_n = 0, art_fe = 0, art_threads = 1;
 	// batches: slot 0 is the resident batch of the synchronous calls; td_submit rotates over pipeline_depth slots
 	TdSlot slots[TD_MAX_PIPELINE];
-	int pipeline_depth = 2, next_slot = 0, last_slot = 0;
+	int pipeline_depth = 3, next_slot = 0, last_slot = 0;
 	int64_t ticket_counter = 0;
 	hipStream_t s_up = nullptr, s_down = nullptr;   // copy streams of the pipelined calls
 	uint8_t* d_ws = nullptr;      size_t cap_ws = 0;  // one workspace for all slots (decode kernels run one after the other)
@@ -281,6 +283,42 @@ static int load_spec_kernel(td_ctx* c, int lsum_oob)
 	if (td_spec_compile(&c->m_desc, code, log, lsum_oob) != TD_OK) return fail(c, "td_model_upload: specialised kernel did not compile: %.400s", log.c_str());
 	HIPCHK(c, hipModuleLoadData(&c->spec_mod, code.data()));
 	HIPCHK(c, hipModuleGetFunction(&c->spec_fn, c->spec_mod, "td_spec_kernel"));
+	// lsum() as compiled against the reference's formula on the operand pairs that matter (either or both operands -inf,
+	// gaps just below / at / above the 15.7 cut, huge gaps, equal operands).  The clamp-free form depends on hardware and
+	// toolchain behaviour nobody documents; if it ever stops holding, the clamped form is loaded instead -- loudly.
+	{
+		static const float g[] = { 0.0f, 0.0005f, 0.001f, 1.0f, 15.699f, 15.6999f, 15.7f, 15.7001f, 16.639f, 16.64f, 16.7f, 100.0f, 1.0e5f, 1.0e6f };
+		std::vector<float> pairs;
+		for (float base : { 0.0f, -3.25f, -700.0f }) {
+			for (float d : g) { pairs.push_back(base); pairs.push_back(base - d); pairs.push_back(base - d); pairs.push_back(base); }
+			pairs.push_back(base); pairs.push_back(-INFINITY); pairs.push_back(-INFINITY); pairs.push_back(base);
+		}
+		pairs.push_back(-INFINITY); pairs.push_back(-INFINITY);
+		const int n_pairs = (int)(pairs.size() / 2);
+		hipFunction_t chk = nullptr;
+		HIPCHK(c, hipModuleGetFunction(&chk, c->spec_mod, "td_spec_selfcheck"));
+		float* d_pairs = nullptr; int* d_bad = nullptr; int bad = -1;
+		HIPCHK(c, hipMalloc((void**)&d_pairs, pairs.size() * 4));
+		HIPCHK(c, hipMalloc((void**)&d_bad, 4));
+		HIPCHK(c, hipMemcpy(d_pairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
+		HIPCHK(c, hipMemset(d_bad, 0, 4));
+		struct { const float* logsum; const float* pairs; int n; int pad; int* bad; } a = { c->d_logsum, d_pairs, n_pairs, 0, d_bad };
+		size_t sz = sizeof a;
+		void* cfg[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END };
+		const int block = td_spec_block_threads();
+		hipError_t e = n_pairs <= block ? hipModuleLaunchKernel(chk, 1, 1, 1, (unsigned)block, 1, 1, 0, c->stream, nullptr, cfg) : hipErrorInvalidValue;
+		if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+		if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost);
+		(void)hipFree(d_pairs); (void)hipFree(d_bad);
+		if (e != hipSuccess) return fail(c, "td_model_upload: logsum self-check did not run: %s", hipGetErrorString(e));
+		if (getenv("TD_SPEC_SELFCHECK_FAIL") && lsum_oob) bad = 1;   // tests: exercise the fallback
+		if (bad != 0) {
+			if (!lsum_oob) return fail(c, "td_model_upload: the compiled logsum differs from the reference formula on %d of %d operand pairs", bad, n_pairs);
+			fprintf(stderr, "tagdust_hip: clamp-free logsum failed its self-check on this device / toolchain (%d of %d pairs); using the clamped form\n", bad, n_pairs);
+			c->spec_oob_unsafe = true;
+			return load_spec_kernel(c, 0);
+		}
+	}
 	c->spec_ready = true;
 	c->spec_oob = lsum_oob != 0;
 	return TD_OK;
@@ -404,7 +442,7 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 		scan(m->trans, (size_t)m->C * 9); scan(m->eM, (size_t)m->C * 5); scan(m->eI, (size_t)m->C * 5);
 		scan(m->sM, m->C); scan(m->sI, m->C); scan(m->skip, m->S); scan(m->bg, 5);
 		c->m_maxabs = mx;
-		if (load_spec_kernel(c, td_spec_lsum_oob()) != TD_OK) return TD_FAIL;
+		if (load_spec_kernel(c, c->spec_oob_unsafe ? 0 : td_spec_lsum_oob()) != TD_OK) return TD_FAIL;
 		c->spec_block = td_spec_block_threads();
 		// resident waves per CU: two LDS tables fit a CU; a 1024-thread workgroup fills it alone
 		{
@@ -743,46 +781,45 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 	return TD_OK;
 }
 
-// Results into the caller's order on the device, then device -> host on `down`.  A page-locked destination is written by
-// the DMA engine directly; anything else is reached through pinned staging and copied out by slot_fetch_end.
-static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* labels, uint8_t* seq_out, hipStream_t down)
+// Results into the caller's order on the device (finish kernel on the compute stream), then device -> host.  A page-locked
+// destination is written by the DMA engine directly; anything else is reached through pinned staging and copied out by
+// slot_fetch_end.  The synchronous calls queue the copies behind the finish kernel on the compute stream.  The pipelined
+// calls must not: a copy queued behind an event is carried out by a blit *kernel*, which then competes for CUs with the
+// next batch's decode kernel -- a persistent kernel that owns every register file -- and finishes when that does (measured:
+// 41 ms instead of 3).  So td_wait waits for the finish kernel on the host and issues the copies then, with nothing
+// pending in front of them: they go to the SDMA engines and run beside the decode kernel.
+static int slot_issue_copies(td_ctx* c, TdSlot& s, hipStream_t down)
+{
+	const int64_t n = s.n_reads;
+	const size_t res_bytes = (size_t)n * sizeof(td_read_result), seq_bytes = (size_t)s.n_bases, lab_bytes = (size_t)(s.n_bases + n);
+	if (s.u_res) HIPCHK(c, hipMemcpyAsync(s.res_direct ? (void*)s.u_res : (void*)s.h_res, s.d_res, res_bytes, hipMemcpyDeviceToHost, down));
+	if (s.u_seq && seq_bytes) HIPCHK(c, hipMemcpyAsync(s.seq_direct ? (void*)s.u_seq : (void*)s.h_seq, s.d_seq, seq_bytes, hipMemcpyDeviceToHost, down));
+	if (s.u_labels) HIPCHK(c, hipMemcpyAsync(s.lab_direct ? (void*)s.u_labels : (void*)s.h_lab, s.d_lab, lab_bytes, hipMemcpyDeviceToHost, down));
+	HIPCHK(c, hipEventRecord(s.ev_down, down));
+	return TD_OK;
+}
+
+static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* labels, uint8_t* seq_out, bool deferred)
 {
 	if (!s.ran) return fail(c, "td_batch_download: td_run has not been called on this batch");
 	s.u_res = res; s.u_labels = labels; s.u_seq = seq_out;
 	s.res_direct = s.lab_direct = s.seq_direct = false;
+	s.copies_deferred = deferred;
 	const int64_t n = s.n_reads;
 	if (n == 0) return TD_OK;
 	const size_t res_bytes = (size_t)n * sizeof(td_read_result), seq_bytes = (size_t)s.n_bases, lab_bytes = (size_t)(s.n_bases + n);
 	if (res && ensure(c, &s.d_res, &s.cap_res, res_bytes) != TD_OK) return TD_FAIL;
 	if (seq_out && ensure(c, &s.d_seq, &s.cap_seq, seq_bytes) != TD_OK) return TD_FAIL;
 	if (labels && ensure(c, &s.d_lab, &s.cap_lab, lab_bytes) != TD_OK) return TD_FAIL;
+	if (res && !(s.res_direct = is_pinned(res)) && ensure_pinned(c, &s.h_res, &s.cap_h_res, res_bytes) != TD_OK) return TD_FAIL;
+	if (seq_out && !(s.seq_direct = is_pinned(seq_out)) && ensure_pinned(c, &s.h_seq, &s.cap_h_seq, seq_bytes) != TD_OK) return TD_FAIL;
+	if (labels && !(s.lab_direct = is_pinned(labels)) && ensure_pinned(c, &s.h_lab, &s.cap_h_lab, lab_bytes) != TD_OK) return TD_FAIL;
 	s.sb.res = res ? s.d_res : nullptr;
 	s.sb.seq_out = seq_out ? s.d_seq : nullptr;
 	s.sb.labels_out = labels ? s.d_lab : nullptr;
 	HIPCHK(c, td_stage_finish(s.sb, c->stream));
-	if (down != c->stream) {
-		HIPCHK(c, hipEventRecord(s.ev_done, c->stream));
-		HIPCHK(c, hipStreamWaitEvent(down, s.ev_done, 0));
-	}
-	if (res) {
-		s.res_direct = is_pinned(res);
-		void* dst = res;
-		if (!s.res_direct) { if (ensure_pinned(c, &s.h_res, &s.cap_h_res, res_bytes) != TD_OK) return TD_FAIL; dst = s.h_res; }
-		HIPCHK(c, hipMemcpyAsync(dst, s.d_res, res_bytes, hipMemcpyDeviceToHost, down));
-	}
-	if (seq_out && seq_bytes) {
-		s.seq_direct = is_pinned(seq_out);
-		void* dst = seq_out;
-		if (!s.seq_direct) { if (ensure_pinned(c, &s.h_seq, &s.cap_h_seq, seq_bytes) != TD_OK) return TD_FAIL; dst = s.h_seq; }
-		HIPCHK(c, hipMemcpyAsync(dst, s.d_seq, seq_bytes, hipMemcpyDeviceToHost, down));
-	}
-	if (labels) {
-		s.lab_direct = is_pinned(labels);
-		void* dst = labels;
-		if (!s.lab_direct) { if (ensure_pinned(c, &s.h_lab, &s.cap_h_lab, lab_bytes) != TD_OK) return TD_FAIL; dst = s.h_lab; }
-		HIPCHK(c, hipMemcpyAsync(dst, s.d_lab, lab_bytes, hipMemcpyDeviceToHost, down));
-	}
-	HIPCHK(c, hipEventRecord(s.ev_down, down));
+	if (deferred) HIPCHK(c, hipEventRecord(s.ev_done, c->stream));
+	else if (slot_issue_copies(c, s, c->stream) != TD_OK) return TD_FAIL;
 	s.finished = true;
 	return TD_OK;
 }
@@ -790,6 +827,10 @@ static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* l
 static int slot_fetch_end(td_ctx* c, TdSlot& s)
 {
 	if (s.n_reads == 0 || !s.finished) return TD_OK;
+	if (s.copies_deferred) {
+		HIPCHK(c, hipEventSynchronize(s.ev_done));
+		if (slot_issue_copies(c, s, c->s_down) != TD_OK) return TD_FAIL;
+	}
 	HIPCHK(c, hipEventSynchronize(s.ev_down));
 	const int64_t n = s.n_reads;
 	if (s.u_res && !s.res_direct) parallel_copy(s.u_res, s.h_res, (size_t)n * sizeof(td_read_result));
@@ -845,7 +886,7 @@ extern "C" int td_batch_download(td_ctx* c, td_read_result* res, int8_t* labels,
 	if (!c) return TD_FAIL;
 	TdSlot& s = c->slots[0];
 	HIPCHK(c, hipSetDevice(c->device));
-	if (slot_fetch_begin(c, s, res, labels, seq_out, c->stream) != TD_OK) return TD_FAIL;
+	if (slot_fetch_begin(c, s, res, labels, seq_out, false) != TD_OK) return TD_FAIL;
 	return slot_fetch_end(c, s);
 }
 
@@ -869,7 +910,7 @@ extern "C" int td_submit(td_ctx* c, const void* bases, int32_t is_ascii, const i
 	TdSlot& s = c->slots[k];
 	if (slot_stage(c, s, bases, is_ascii != 0, offs, n_reads, c->s_up) != TD_OK) return TD_FAIL;
 	if (slot_decode(c, s, mode) != TD_OK) return TD_FAIL;
-	if (slot_fetch_begin(c, s, res, labels, seq_out, c->s_down) != TD_OK) return TD_FAIL;
+	if (slot_fetch_begin(c, s, res, labels, seq_out, true) != TD_OK) return TD_FAIL;
 	s.ticket = ++c->ticket_counter;
 	c->next_slot = (k + 1) % c->pipeline_depth;
 	*ticket = s.ticket;

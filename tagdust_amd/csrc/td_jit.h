@@ -15,4 +15,5 @@ int td_spec_lsum_oob(void);      /* 1: clamp-free logsum (LDS out-of-range reads
 std::string td_spec_model_section(const td_model_desc* m, int lsum_oob = -1);   /* lsum_oob < 0: td_spec_lsum_oob() */
 std::string td_spec_full_source(const td_model_desc* m, int lsum_oob = -1);
 void td_spec_layout(TdSpecLayout& L, const td_model_desc* m, int lmax);
+std::string td_spec_cache_dir(void);   /* on-disk cache of compiled kernels ("" = off) */
 int td_spec_compile(const td_model_desc* m, std::vector<char>& code, std::string& log, int lsum_oob = -1);

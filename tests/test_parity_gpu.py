@@ -343,6 +343,34 @@ def test_long_reads_switch_to_clamped_logsum(monkeypatch):
     assert np.array_equal(seq0, seq1) and np.array_equal(seq0, g["seq_after"])
 
 
+def test_logsum_selfcheck_falls_back_to_clamped_form(monkeypatch, capfd):
+    """Every load of a compiled kernel runs lsum() over the operand pairs that matter (-inf operands, gaps around the 15.7
+    cut, huge gaps) against the reference's formula; a failing clamp-free form must be replaced by the clamped one, with a
+    message, and the results stay bit-exact.  The failure is forced through TD_SPEC_SELFCHECK_FAIL."""
+    from tagdust_amd import TagdustHip
+    g = load_golden("c2_b4_r")
+    monkeypatch.setenv("TD_SPEC_NT", "0")               # a source variant of its own: not served from the in-memory cache
+    monkeypatch.setenv("TD_SPEC_SELFCHECK_FAIL", "1")
+    c = TagdustHip(0)
+    try:
+        c.set_option("specialize", 1)
+        res, labels, seq = _run(c, g)
+        assert c.get_option("spec_lsum_clamped") == 1
+    finally:
+        c.close()
+    assert "self-check" in capfd.readouterr().err
+    assert np.array_equal(labels, g["labels"]) and np.array_equal(seq, g["seq_after"])
+    assert np.array_equal(_bits(res["f_score"]), _bits(g["f_score"]))
+    monkeypatch.delenv("TD_SPEC_SELFCHECK_FAIL")
+    c = TagdustHip(0)
+    try:
+        c.set_option("specialize", 1)
+        _run(c, g)
+        assert c.get_option("spec_lsum_clamped") == 0      # the real self-check passes on gfx950
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("workload,n", [("c3", 1 << 20), ("c2", 1 << 20), ("c5", 1 << 19)], ids=["config3", "config2", "config5"])
 def test_full_size_batch_properties(workload, n):
     """BASELINE.json's shapes at full batch size (2^20 reads; 2^19 for the 100-HMM architecture of configs[4], whose

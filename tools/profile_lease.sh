@@ -1,0 +1,31 @@
+#!/bin/bash
+# One lease, one box, one binary: the driver's bench command, then rocprofv3 --kernel-trace --stats and the PMC passes
+# (each in its own run, program directly after "--") on the same workload, summarised into profiles/<tag>_*.
+#   tools/grun.sh --timeout 900 -- 'tools/profile_lease.sh r02'
+# Writes gpurun_out/lease_<tag>/ (raw) and gpurun_out/lease_<tag>/profiles/ (the files to copy into profiles/).
+set -u
+TAG=${1:-rXX}
+STEPS=${2:-20}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/lease_$TAG
+P=$OUT/profiles
+mkdir -p $P
+export TMPDIR=/tmp
+export TD_SPEC_CACHE_DIR=/tmp/td_spec_cache
+mkdir -p $TD_SPEC_CACHE_DIR
+cd $ROOT
+echo "== bench (the driver's command)"
+timeout -k 10 500 python3 bench.py --gpus 1 --steps $STEPS --warmup 5 > $P/${TAG}_bench_line.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
+PROF_ARGS="--steps $STEPS --warmup 5 --extras 0 --cpu-sample 0 --check 0"
+run() { local name=$1; shift
+	timeout -k 10 300 rocprofv3 "$@" --output-format csv -d $OUT/$name -o td -- python3 $ROOT/bench.py $PROF_ARGS > $OUT/$name.log 2>&1 \
+		|| { echo "rocprofv3 pass $name failed"; tail -5 $OUT/$name.log; return 1; }
+	echo "pass $name done"; }
+run trace --kernel-trace --stats &&
+run fetch --pmc FETCH_SIZE &&
+run write --pmc WRITE_SIZE &&
+run pmc1 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS &&
+run pmc2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS &&
+run pmc3 --pmc SQ_INSTS_FLAT SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT GRBM_GUI_ACTIVE
+python3 tools/summarize_lease.py $OUT $TAG
+ls $P

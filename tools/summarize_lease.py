@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Summarise one tools/profile_lease.sh lease: kernel durations from --kernel-trace --stats, PMC sums per dispatch of the
+dominant kernel, HBM bytes per launch (FETCH_SIZE x2 on gfx950, MI355X_MICROARCH.md "HBM"; KiB -> bytes), and the bench
+line of the same lease.  Writes <tag>_td_spec_kernel_summary.json, <tag>_kernel_stats.csv and traffic.json."""
+import csv
+import datetime
+import glob
+import json
+import os
+import shutil
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def rows(pattern):
+    out = []
+    for p in glob.glob(pattern, recursive=True):
+        with open(p) as fh:
+            out += list(csv.DictReader(fh))
+    return out
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    kname = "td_spec_kernel"
+    P = os.path.join(out, "profiles")
+    import bench
+    res = {"tag": tag, "collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
+           "head": open(os.path.join(REPO, ".build_head")).read().strip() if os.path.exists(os.path.join(REPO, ".build_head")) else "?",
+           "kernel_source_sha16": bench.kernel_source_sha16(),
+           "profiled_command": "rocprofv3 <pass> -- python3 bench.py --steps <as the bench line> --warmup 5 --extras 0 --cpu-sample 0 --check 0 "
+                               "(the headline workload and pipeline of the bench line, without the extra workloads; averages are over "
+                               "the dispatches of the timed steps, the warm-up dispatches are left out as in bench.py)"}
+    try:
+        line = json.load(open(os.path.join(P, tag + "_bench_line.json")))
+        res["bench_line_same_lease"] = {k: line[k] for k in ("value", "ms_per_step", "steps", "warmup")}
+        res["bench_line_same_lease"]["kernel_ms"] = line["roofline"]["kernel_ms"]
+    except Exception as e:
+        res["bench_line_same_lease"] = {"error": str(e)}
+    kt_all = rows(os.path.join(out, "trace", "**", "*kernel_trace.csv"))
+    kt = [r for r in kt_all if kname in r.get("Kernel_Name", "")]
+    kt.sort(key=lambda r: int(r["Start_Timestamp"]))
+    steps = res.get("bench_line_same_lease", {}).get("steps")
+    if steps and len(kt) > steps:
+        kt = kt[-steps:]            # the timed steps (bench.py's warm-up comes first)
+    if kt:
+        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in kt]
+        res["kernel_trace"] = {"kernel": kname, "dispatches": len(durs), "avg_ms": sum(durs) / len(durs), "min_ms": min(durs),
+                               "max_ms": max(durs), "vgpr": kt[0].get("VGPR_Count"), "accum_vgpr": kt[0].get("Accum_VGPR_Count"),
+                               "sgpr": kt[0].get("SGPR_Count"), "lds": kt[0].get("LDS_Block_Size"),
+                               "scratch_bytes_per_lane": kt[0].get("Scratch_Size"), "grid": kt[0].get("Grid_Size"),
+                               "workgroup": kt[0].get("Workgroup_Size")}
+        others = {}
+        for r in kt_all:
+            if kname in r["Kernel_Name"]:
+                continue
+            others.setdefault(r["Kernel_Name"][:60], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+        res["other_kernels_avg_ms"] = {k: {"n": len(v), "avg_ms": sum(v) / len(v)} for k, v in others.items()}
+    for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(P, tag + "_kernel_stats.csv"))
+    pmc = {}
+    for name in ("fetch", "write", "pmc1", "pmc2", "pmc3"):
+        per = {}
+        for r in rows(os.path.join(out, name, "**", "*counter_collection.csv")):
+            if kname not in r.get("Kernel_Name", ""):
+                continue
+            per.setdefault(r["Counter_Name"], []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+        for k, v in per.items():
+            v.sort()
+            vals = [x[1] for x in v]
+            pmc[k] = vals[-steps:] if steps and len(vals) > steps else vals
+    p = {k: sum(v) / len(v) for k, v in pmc.items()}
+    res["pmc_per_dispatch_avg"] = p
+    n = 1 << 20
+    if "FETCH_SIZE" in p and "WRITE_SIZE" in p and kt:
+        f = p["FETCH_SIZE"] * 1024 * 2
+        w = p["WRITE_SIZE"] * 1024
+        k_ms = res["kernel_trace"]["avg_ms"]
+        res["hbm"] = {"fetch_bytes_corrected_x2": f, "write_bytes": w, "bytes_per_launch": f + w, "bytes_per_read": (f + w) / n,
+                      "tb_per_s_at_traced_kernel_ms": (f + w) / (k_ms * 1e-3) / 1e12, "frac_of_8tb_peak": (f + w) / (k_ms * 1e-3) / 8e12}
+        traffic = {"round": tag, "kernel": kname, "workload": "c3", "reads_per_launch": n, "hbm_bytes_per_launch": f + w,
+                   "fetch_bytes_corrected_x2": f, "write_bytes": w, "kernel_ms_same_lease": k_ms, "head": res["head"],
+                   "kernel_source_sha16": res["kernel_source_sha16"], "collected": res["collected"],
+                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of tools/profile_lease.sh; KiB -> bytes; "
+                             "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads)"}
+        json.dump(traffic, open(os.path.join(P, "traffic.json"), "w"), indent=1)
+    if p.get("SQ_WAVE_CYCLES"):
+        res["derived"] = {"wait_any_share_of_wave_cycles": p.get("SQ_WAIT_ANY", 0) / p["SQ_WAVE_CYCLES"],
+                          "lds_bank_conflict_share": (p.get("SQ_LDS_BANK_CONFLICT", 0) / p["SQ_LDS_IDX_ACTIVE"]) if p.get("SQ_LDS_IDX_ACTIVE") else None,
+                          "valu_insts_per_read": p.get("SQ_INSTS_VALU", 0) / n, "lds_insts_per_read": p.get("SQ_INSTS_LDS", 0) / n,
+                          "vmem_rd_insts_per_read": p.get("SQ_INSTS_VMEM_RD", 0) / n, "vmem_wr_insts_per_read": p.get("SQ_INSTS_VMEM_WR", 0) / n}
+    json.dump(res, open(os.path.join(P, tag + "_td_spec_kernel_summary.json"), "w"), indent=1)
+    print(json.dumps({k: res.get(k) for k in ("bench_line_same_lease", "kernel_trace", "hbm", "derived")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
