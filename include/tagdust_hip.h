@@ -130,12 +130,17 @@ int64_t td_spec_source(const td_model_desc* model, char* buf, int64_t cap);
  * read_type = (1-based sequence index << 8) | 5.  n_seq = 0 switches the filter off. */
 int td_set_artifacts(td_ctx* ctx, const uint8_t* string, const int32_t* s_index, int32_t n_seq,
                      int32_t filter_error, int32_t n_threads);
+/* The batches this context gets from now on are reads [first_read, first_read + n) of a batch of total_reads reads that is
+ * shared out over several contexts (tagdust_multi.h): the artifact filter's thread ranges are then taken over the whole
+ * batch, so that every read is scored by the routine the reference would use for it.  total_reads = 0: a batch is whole. */
+int td_set_batch_window(td_ctx* ctx, int64_t first_read, int64_t total_reads);
 /* param->confidence_threshold in effect, param->minlen, param->dust (0 = off) */
 int td_set_params(td_ctx* ctx, float threshold, int32_t minlen, int32_t dust);
 
 /* ---- batches ---- */
 /* Stage a batch of reads: codes = base codes 0..4 (A,C,G,T,other: src/nuc_code.c:46-74) of all reads
- * concatenated, offs[n_reads+1] the read boundaries (like ri[i]->seq / ri[i]->len; offs[0] = 0).  One host-to-device
+ * concatenated, offs[n_reads+1] the read boundaries (like ri[i]->seq / ri[i]->len; read i is codes[offs[i] .. offs[i+1])).
+ * One host-to-device
  * copy of the bytes as they are; sorting by length and packing to 2 bit + N mask happen on the device.  Replaces
  * whatever batch was resident; returns when the caller's buffers may be reused. */
 int td_batch_upload(td_ctx* ctx, const uint8_t* codes, const int64_t* offs, int64_t n_reads);
@@ -157,7 +162,9 @@ int td_batch_download(td_ctx* ctx, td_read_result* res, int8_t* labels, uint8_t*
 /* Hand over a batch and name where its results go; returns once the reads have left the caller's buffers (they may be
  * reused) with the upload, the decode kernel (mode as td_run; parameters, model and artifact filter as set at this
  * moment) and the download queued on the device.  bases: base codes 0..4, or FASTQ sequence text when is_ascii != 0.
- * res / labels / seq_out as in td_batch_download (any may be NULL); they are complete after td_wait(ticket).
+ * res / labels / seq_out as in td_batch_download (any may be NULL); they are complete after td_wait(ticket).  offs[0]
+ * need not be 0: read i is bases[offs[i] .. offs[i+1]) and output positions count from offs[0] (seq_out + offs[i] - offs[0],
+ * labels + offs[i] - offs[0] + i), so a contiguous range of a larger batch can be handed over with its own offsets.
  * At most "pipeline_depth" tickets may be outstanding (TD_FAIL beyond that).  Page-locked buffers (td_host_alloc, or
  * registered with hipHostRegister) are read and written by the DMA engines directly; any other host memory goes through
  * the library's own pinned staging with one extra host copy each way (TD_HOST_THREADS host threads, default all, <= 16). */

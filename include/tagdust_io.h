@@ -31,9 +31,13 @@ typedef struct td_reads {
 	uint8_t* codes;        /* base codes 0..4 ('.' -> 5 like the reference) */
 } td_reads;
 
-/* Parse a whole FASTQ/FASTA text held in memory with n_threads host threads (<= 0: pick).  */
+/* Parse a whole FASTQ/FASTA text held in memory with n_threads host threads (<= 0: pick).  TD_FAIL (with a message in
+ * td_io_last_error) when a record's quality line is not as long as its sequence -- the reference ends the run there
+ * (src/io.c:1776-1781). */
 int  td_reads_parse(const char* text, int64_t len, int32_t n_threads, td_reads** out);
 void td_reads_free(td_reads* reads);
+/* message of the last failed td_reads_parse / td_writer_write of this thread */
+const char* td_io_last_error(void);
 
 /* struct fasta (src/io.h:59-71) as read_fasta() leaves it: ready for td_set_artifacts */
 typedef struct td_fasta {

@@ -80,7 +80,8 @@ int   td_calibration_emit(const td_arch* arch, const td_seq_stats* stats, float 
 /* the sort + sweep of calibrateQ.c:146-212 on the per-read Q values */
 float td_calibration_select(const float* mapq, const uint8_t* is_random, int64_t n_reads);
 void  td_calibration_free(td_calibration* cal);
-/* emit -> td_model_upload(scoring) -> td_run(TD_MODE_GET_PROB) -> select.  Leaves the scoring model uploaded. */
+/* emit -> td_model_upload(scoring) -> td_run(TD_MODE_GET_PROB) -> select.  Replaces the context's model and resident
+ * batch: the scoring model and the calibration reads are what it holds afterwards. */
 int   td_estimate_threshold(td_ctx* ctx, const td_arch* arch, const td_seq_stats* stats, float indel_frequency,
                             uint32_t seed, int32_t n_reads, int32_t rng, float* threshold);
 
@@ -89,7 +90,8 @@ int   td_estimate_threshold(td_ctx* ctx, const td_arch* arch, const td_seq_stats
  * reads are scored with backward() alone (TD_MODE_ARCH_COMP, generic kernel: no per-candidate compile) and the
  * per-candidate float sums are formed over the reference's n_threads contiguous ranges in read order, then over the
  * ranges (barcode_hmm.c:2111-2148, :1995-2016) -- the float result depends on that order.  posterior[k] is the
- * normalised probability the reference logs as "Confidence"; *best the index it selects. */
+ * normalised probability the reference logs as "Confidence"; *best the index it selects.  Replaces the context's model
+ * and resident batch (the last candidate's); the "specialize" option is restored to what it was. */
 int   td_compare_architectures(td_ctx* ctx, const td_arch* const* archs, int32_t n_arch, const uint8_t* codes,
                                const int64_t* offs, int64_t n_reads, float sequencer_error_rate, float indel_frequency,
                                int32_t n_threads, float* posterior, int32_t* best);

@@ -1,0 +1,64 @@
+/*
+ * tagdust_multi.h -- one process, several MI355X: the static shard of a batch over the GPUs of a node and the one
+ * exchange of the path (part of libtagdust_hip.so).
+ *
+ * The reference splits a batch over T pthreads in contiguous ranges (run_pHMM, src/barcode_hmm.c:1911-1922:
+ * interval = numseq / T, thread t takes [t*interval, (t+1)*interval), the last one also the remainder) and joins them
+ * before the controller combines the files of a paired / 3-read run per record index (:329-351) and print_all() writes
+ * the records in input order (src/io.c:757-1016).  Here the ranges go to devices instead of threads: reads are
+ * independent given the model, so there is no data-path collective -- every device decodes its range with its own context
+ * (model, threshold and artifact sequences replicated) and writes its results straight into the caller's arrays at the
+ * range's offset, which keeps input order.  Every input file of a multi-file run has the same number of records, so the
+ * same n gives the same ranges in every file (td_shard_bounds): record i of file 1 and record i of file 2 land on the
+ * same device index and at the same output index.  The only exchange is the sum of the 8 outcome + 256 per-barcode
+ * counters (src/barcode_hmm.c:354-384 counts serially): one ncclAllReduce (RCCL over xGMI) on the contexts' device
+ * counters when more than one device takes part, a plain read-back for one device.
+ */
+#ifndef TAGDUST_MULTI_H
+#define TAGDUST_MULTI_H
+
+#include <stdint.h>
+#include "tagdust_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- host-side pieces (no GPU needed) ---- */
+/* run_pHMM's contiguous split (barcode_hmm.c:1911-1922) of n reads over `world` parts: part `rank` is [*lo, *hi). */
+void td_shard_bounds(int64_t n_reads, int32_t world, int32_t rank, int64_t* lo, int64_t* hi);
+/* The device counters, restated on the host from per-read results: slot = read_type & 7 for every read with at least
+ * one base (an artifact hit is (sequence << 8) | 5), then per-barcode bins (barcode & 0xFF) of the extracted reads.
+ * Adds to counts[TD_NUM_COUNTERS].  lens may be NULL (all reads counted). */
+void td_count_outcomes(const td_read_result* res, const int32_t* lens, int64_t n_reads, int64_t* counts);
+
+/* ---- several devices driven from one process ---- */
+typedef struct td_multi td_multi;
+/* devices[n_devices] = HIP device indices (NULL: 0 .. n_devices-1).  One context and one host thread per device.
+ * With n_devices > 1 distinct devices an RCCL communicator is created (librccl.so is loaded then, not before). */
+int  td_multi_create(const int32_t* devices, int32_t n_devices, td_multi** out);
+void td_multi_destroy(td_multi* m);
+const char* td_multi_last_error(const td_multi* m);   /* m == NULL: the failed td_multi_create */
+int32_t td_multi_size(const td_multi* m);
+td_ctx* td_multi_ctx(td_multi* m, int32_t k);          /* the k-th device's context (options, per-device inspection) */
+/* replicate model / parameters / artifact sequences on every device (uploads and kernel compiles run concurrently) */
+int  td_multi_model_upload(td_multi* m, const td_model_desc* model);
+int  td_multi_set_params(td_multi* m, float threshold, int32_t minlen, int32_t dust);
+int  td_multi_set_artifacts(td_multi* m, const uint8_t* string, const int32_t* s_index, int32_t n_seq,
+                            int32_t filter_error, int32_t n_threads);
+/* One run_pHMM call over all devices: reads [0, n) are split with td_shard_bounds, every device runs td_submit / td_wait
+ * on its range, results arrive in input order (res / labels / seq_out as in td_batch_download; any may be NULL).
+ * Per-read results are identical to a single context's: the artifact filter's thread ranges are taken over the whole
+ * batch, not over a device's share. */
+int  td_multi_decode(td_multi* m, const void* bases, int32_t is_ascii, const int64_t* offs, int64_t n_reads, int mode,
+                     td_read_result* res, int8_t* labels, uint8_t* seq_out);
+/* Counters summed over the devices (all-reduced on the devices with RCCL when the communicator exists). */
+int  td_multi_counts(td_multi* m, int64_t* counts /* [TD_NUM_COUNTERS] */);
+int  td_multi_counts_reset(td_multi* m);
+/* 1 when td_multi_counts goes through ncclAllReduce, 0 when it sums on the host (one device, or a device listed twice) */
+int32_t td_multi_uses_rccl(const td_multi* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -125,6 +125,7 @@ struct td_ctx {
 	// -ref artifact filter
 	uint8_t* d_art_text = nullptr; int32_t* d_art_index = nullptr;
 	int32_t art_n = 0, art_fe = 0, art_threads = 1;
+	int64_t win_first = 0, win_total = 0;   // td_set_batch_window
 	// batches: slot 0 is the resident batch of the synchronous calls; td_submit rotates over pipeline_depth slots
 	TdSlot slots[TD_MAX_PIPELINE];
 	int pipeline_depth = 3, next_slot = 0, last_slot = 0;
@@ -506,6 +507,14 @@ extern "C" int td_set_artifacts(td_ctx* c, const uint8_t* string, const int32_t*
 	return TD_OK;
 }
 
+extern "C" int td_set_batch_window(td_ctx* c, int64_t first_read, int64_t total_reads)
+{
+	if (!c) return TD_FAIL;
+	if (first_read < 0 || total_reads < 0) return fail(c, "td_set_batch_window: negative argument");
+	c->win_first = first_read; c->win_total = total_reads;
+	return TD_OK;
+}
+
 extern "C" int td_set_params(td_ctx* c, float threshold, int32_t minlen, int32_t dust)
 {
 	if (!c) return TD_FAIL;
@@ -655,11 +664,11 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 	s.staged = false; s.ran = false; s.finished = false;
 	s.n_reads = 0; s.n_tiles = 0;
 	if (!c->have_model) return fail(c, "td_batch_upload: no model uploaded");
-	if ((!bases && n > 0 && offs && offs[n] > offs[0]) || !offs || n < 0) return fail(c, "td_batch_upload: bad arguments");
+	if (!offs || n < 0 || (!bases && n > 0 && offs[n] > offs[0])) return fail(c, "td_batch_upload: bad arguments");
 	if (n > 0x7fffffffLL - TD_WAVE) return fail(c, "td_batch_upload: %lld reads in one batch", (long long)n);
 	HIPCHK(c, hipSetDevice(c->device));
 	if (slot_events(c, s) != TD_OK) return TD_FAIL;
-	if (offs[0] != 0) return fail(c, "td_batch_upload: offs[0] must be 0");
+	const int64_t base = offs[0];   // a sub-range of a larger batch keeps the caller's offsets (td_multi_decode)
 	// offsets: one pass that copies them into pinned memory and finds the longest / shortest read
 	if (ensure_pinned(c, &s.h_offs, &s.cap_h_offs, (size_t)(n + 1) * 8) != TD_OK) return TD_FAIL;
 	int lmax = 1, lmin = 0x7fffffff;
@@ -667,13 +676,13 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 	s.h_offs[0] = 0;
 	for (int64_t i = 0; i < n; i++) {
 		const int64_t l = offs[i + 1] - offs[i];
-		s.h_offs[i + 1] = offs[i + 1];
+		s.h_offs[i + 1] = offs[i + 1] - base;
 		if (l < 0 || l > 100000) { bad = i; break; }
 		if (l > lmax) lmax = (int)l;
 		if (l < lmin) lmin = (int)l;
 	}
 	if (bad >= 0) return fail(c, "td_batch_upload: read %lld has length %lld", (long long)bad, (long long)(offs[bad + 1] - offs[bad]));
-	const int64_t n_bases = n > 0 ? offs[n] : 0;
+	const int64_t n_bases = n > 0 ? offs[n] - base : 0;
 	const int64_t n_tiles = (n + TD_WAVE - 1) / TD_WAVE;
 	const int nw2 = (lmax + 15) / 16, nw1 = (lmax + 31) / 32;
 	const bool sorted = n > 0 && lmin != lmax;
@@ -697,10 +706,10 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 	s.n_tiles = 0;
 
 	// host -> device: page-locked caller memory goes straight to the DMA engine, anything else through pinned staging
-	const void* src = bases;
-	if (n_bases > 0 && !is_pinned(bases)) {
+	const void* src = (const uint8_t*)bases + base;
+	if (n_bases > 0 && !is_pinned(src)) {
 		if (ensure_pinned(c, &s.h_raw, &s.cap_h_raw, (size_t)n_bases) != TD_OK) return TD_FAIL;
-		parallel_copy(s.h_raw, bases, (size_t)n_bases);
+		parallel_copy(s.h_raw, src, (size_t)n_bases);
 		src = s.h_raw;
 	}
 	HIPCHK(c, hipMemcpyAsync(s.d_offs, s.h_offs, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, up));
@@ -751,6 +760,7 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 	ka.ws = c->d_ws; ka.lay = s.lay;
 	if (c->art_n > 0 && mode == TD_MODE_GET_LABEL) {
 		s.sb.art_threads = c->art_threads;
+		s.sb.art_first = c->win_first; s.sb.art_total = c->win_total;
 		HIPCHK(c, td_stage_art_left(s.sb, c->stream));
 		ka.art_text = c->d_art_text; ka.art_index = c->d_art_index; ka.art_left = s.d_art_left;
 		ka.art_n = c->art_n; ka.art_fe = c->art_fe;

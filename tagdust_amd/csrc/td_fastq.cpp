@@ -24,7 +24,9 @@ struct Code {
 };
 const Code kCode;
 
-struct Rec { int64_t name_off; int32_t name_len; int64_t seq_off; int32_t seq_len; int64_t qual_off; };
+struct Rec { int64_t name_off; int32_t name_len; int64_t seq_off; int32_t seq_len; int64_t qual_off; int32_t qual_len; };
+
+thread_local std::string g_io_error;
 
 // read_fasta_fastq()'s line state machine (io.c:1697-1799) over text[lo, hi); lo must be the start of a line
 void parse_range(const char* text, int64_t lo, int64_t hi, std::vector<Rec>& out)
@@ -37,7 +39,7 @@ void parse_range(const char* text, int64_t lo, int64_t hi, std::vector<Rec>& out
 		const char first = (p < e) ? text[p] : '\n';
 		auto field_len = [&](int64_t from) { int64_t q = from; while (q < e && !is_cntrl((unsigned char)text[q])) q++; return (int32_t)(q - from); };
 		if ((first == '@' || first == '>') && !set) {
-			Rec r; r.name_off = p + 1; r.name_len = field_len(p + 1); r.seq_off = -1; r.seq_len = 0; r.qual_off = -1;
+			Rec r; r.name_off = p + 1; r.name_len = field_len(p + 1); r.seq_off = -1; r.seq_len = 0; r.qual_off = -1; r.qual_len = 0;
 			out.push_back(r);
 			seq_p = true; set = true;
 		} else if (first == '+' && !set) {
@@ -45,7 +47,7 @@ void parse_range(const char* text, int64_t lo, int64_t hi, std::vector<Rec>& out
 		} else {
 			if (set && !out.empty()) {
 				if (seq_p) { out.back().seq_off = p; out.back().seq_len = field_len(p); }
-				else out.back().qual_off = p;
+				else { out.back().qual_off = p; out.back().qual_len = field_len(p); }
 			}
 			set = false;
 		}
@@ -92,7 +94,19 @@ extern "C" int td_reads_parse(const char* text, int64_t len, int32_t n_threads, 
 		for (auto& t : th) t.join();
 	}
 	int64_t n = 0;
-	for (auto& v : recs) n += (int64_t)v.size();
+	for (auto& v : recs) {
+		// "Length of sequence and base qualities differ" ends the reference's run (io.c:1776-1781): a short or cut-off
+		// quality line must not reach the writer, which reads one quality character per base
+		for (const Rec& q : v)
+			if (q.qual_off >= 0 && q.qual_len != (q.seq_off >= 0 ? q.seq_len : 0)) {
+				char msg[256];
+				snprintf(msg, sizeof msg, "td_reads_parse: record %lld (\"%.*s\"): sequence has %d characters, base qualities %d",
+				         (long long)(n + (&q - v.data())), q.name_len < 60 ? q.name_len : 60, text + q.name_off, q.seq_off >= 0 ? q.seq_len : 0, q.qual_len);
+				g_io_error = msg;
+				return TD_FAIL;
+			}
+		n += (int64_t)v.size();
+	}
 	td_reads* r = (td_reads*)calloc(1, sizeof(td_reads));
 	if (!r) return TD_FAIL;
 	r->n_reads = n; r->text = text;
@@ -129,6 +143,8 @@ extern "C" int td_reads_parse(const char* text, int64_t len, int32_t n_threads, 
 	*out = r;
 	return TD_OK;
 }
+
+extern "C" const char* td_io_last_error(void) { return g_io_error.c_str(); }
 
 extern "C" void td_reads_free(td_reads* r)
 {
@@ -233,8 +249,13 @@ extern "C" int td_writer_write(td_writer* w, const td_reads* rd, const td_read_r
 	format_range(w, rd, res, seq_out, 0, per < rd->n_reads ? per : rd->n_reads, &parts[0]);
 	for (auto& t : th) t.join();
 	for (int t = 0; t < nt; t++)
-		for (size_t f = 0; f < w->files.size(); f++)
-			if (!parts[(size_t)t][f].empty()) fwrite(parts[(size_t)t][f].data(), 1, parts[(size_t)t][f].size(), w->files[f]);
+		for (size_t f = 0; f < w->files.size(); f++) {
+			const std::string& b = parts[(size_t)t][f];
+			if (!b.empty() && fwrite(b.data(), 1, b.size(), w->files[f]) != b.size()) {   // e.g. a full disk
+				g_io_error = "td_writer_write: short write";
+				return TD_FAIL;
+			}
+		}
 	return TD_OK;
 }
 

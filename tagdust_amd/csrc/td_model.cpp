@@ -689,6 +689,7 @@ extern "C" int td_calibration_emit(const td_arch* a, const td_seq_stats* ssi, fl
 		}
 	}
 	td_calibration* cal = (td_calibration*)calloc(1, sizeof(td_calibration));
+	if (!cal) { td_model_tables_free(em); return TD_FAIL; }
 	std::vector<uint8_t> all, one;
 	std::vector<int64_t> offs(1, 0);
 	std::vector<uint8_t> rnd;
@@ -805,6 +806,9 @@ extern "C" int td_compare_architectures(td_ctx* ctx, const td_arch* const* archs
 	// 1 000 000 were seen (1 100 000 reads), and the candidates are scored on the first batch only (:182-184)
 	const int64_t n_score = n_reads < 100000 ? n_reads : 100000;
 	std::vector<td_read_result> res((size_t)n_score);
+	// the many short-lived candidate models run the generic kernel (no per-model compile); the caller's setting comes back
+	int32_t specialize_was = 1;
+	if (td_get_option(ctx, "specialize", &specialize_was) != TD_OK) return TD_FAIL;
 	int rc = td_set_option(ctx, "specialize", 0);
 	for (int k = 0; k < n_arch && rc == TD_OK; k++) {
 		td_seq_stats st;
@@ -824,7 +828,7 @@ extern "C" int td_compare_architectures(td_ctx* ctx, const td_arch* const* archs
 		}
 		posterior[k] = total;
 	}
-	(void)td_set_option(ctx, "specialize", 1);
+	(void)td_set_option(ctx, "specialize", specialize_was);
 	if (rc != TD_OK) return TD_FAIL;
 	if (n_arch > 1) {
 		float sum = posterior[0];                                      // barcode_hmm.c:2009-2016

@@ -20,6 +20,7 @@ struct TdStageBatch {
 	// -ref artifact filter: reads of each thread range are taken in fours, the remainder goes to another routine
 	// (match_to_reference, src/barcode_hmm.c:2495-2575; ranges as in run_pHMM :1911-1922).  art_threads = 0: off
 	int32_t art_threads;
+	int64_t art_first, art_total;   // this batch is reads [art_first, art_first + n_reads) of a batch of art_total (0: it is the whole batch)
 	// decode-kernel side (device order)
 	uint32_t* packed;         // [n_tiles][nw2 + nw1][64]
 	int32_t*  lens;           // [n_tiles * 64]

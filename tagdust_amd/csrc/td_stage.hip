@@ -111,8 +111,8 @@ __global__ __launch_bounds__(STAGE_BLOCK) void td_art_left_kernel(const TdStageB
 	if (k >= (int64_t)b.n_tiles * TD_WAVE) return;
 	uint8_t left = 0;
 	if (k < b.n_reads && b.art_threads > 0) {
-		const int64_t i = b.read_at ? (int64_t)b.read_at[k] : k;
-		const int64_t n = b.n_reads, T = b.art_threads, interval = n / T;
+		const int64_t i = b.art_first + (b.read_at ? (int64_t)b.read_at[k] : k);
+		const int64_t n = b.art_total > 0 ? b.art_total : b.n_reads, T = b.art_threads, interval = n / T;
 		int64_t t = interval > 0 ? i / interval : T - 1;
 		if (t > T - 1) t = T - 1;
 		const int64_t start = t * interval, end = (t == T - 1) ? n : (t + 1) * interval;

@@ -20,9 +20,12 @@ ABI_SYMBOLS = [
     "td_ctx_create", "td_ctx_destroy", "td_last_error", "td_logsum_table", "td_model_upload", "td_set_params",
     "td_batch_upload", "td_batch_upload_ascii", "td_run", "td_sync", "td_batch_download", "td_counts_reset",
     "td_counts_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_batch_info", "td_set_option", "td_get_option", "td_set_artifacts", "td_spec_source",
-    "td_submit", "td_wait", "td_host_alloc", "td_host_free",
+    "td_submit", "td_wait", "td_host_alloc", "td_host_free", "td_set_batch_window",
 ]
-IO_ABI_SYMBOLS = ["td_reads_parse", "td_reads_free", "td_writer_open", "td_writer_write", "td_writer_close",
+MULTI_ABI_SYMBOLS = ["td_shard_bounds", "td_count_outcomes", "td_multi_create", "td_multi_destroy", "td_multi_last_error",
+                     "td_multi_size", "td_multi_ctx", "td_multi_model_upload", "td_multi_set_params", "td_multi_set_artifacts",
+                     "td_multi_decode", "td_multi_counts", "td_multi_counts_reset", "td_multi_uses_rccl"]
+IO_ABI_SYMBOLS = ["td_io_last_error", "td_reads_parse", "td_reads_free", "td_writer_open", "td_writer_write", "td_writer_close",
                   "td_fasta_parse", "td_fasta_free"]
 MODEL_ABI_SYMBOLS = ["td_arch_parse", "td_arch_free", "td_sequence_stats", "td_model_build", "td_model_tables_free",
                      "td_calibration_emit", "td_calibration_select", "td_calibration_free", "td_estimate_threshold",
@@ -111,6 +114,26 @@ def load_library():
     lib.td_host_alloc.restype = C.c_void_p
     lib.td_host_free.argtypes = [C.c_void_p]
     lib.td_host_free.restype = None
+    lib.td_set_batch_window.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+    lib.td_shard_bounds.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.td_shard_bounds.restype = None
+    lib.td_count_outcomes.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.td_count_outcomes.restype = None
+    lib.td_multi_create.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.td_multi_destroy.argtypes = [C.c_void_p]
+    lib.td_multi_destroy.restype = None
+    lib.td_multi_last_error.argtypes = [C.c_void_p]
+    lib.td_multi_last_error.restype = C.c_char_p
+    lib.td_multi_size.argtypes = [C.c_void_p]
+    lib.td_multi_ctx.argtypes = [C.c_void_p, C.c_int32]
+    lib.td_multi_ctx.restype = C.c_void_p
+    lib.td_multi_model_upload.argtypes = [C.c_void_p, C.POINTER(_ModelDesc)]
+    lib.td_multi_set_params.argtypes = [C.c_void_p, C.c_float, C.c_int32, C.c_int32]
+    lib.td_multi_set_artifacts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.td_multi_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.td_multi_counts.argtypes = [C.c_void_p, C.c_void_p]
+    lib.td_multi_counts_reset.argtypes = [C.c_void_p]
+    lib.td_multi_uses_rccl.argtypes = [C.c_void_p]
     lib.td_counts_reset.argtypes = [C.c_void_p]
     lib.td_counts_get.argtypes = [C.c_void_p, C.c_void_p]
     lib.td_counts_device_ptr.argtypes = [C.c_void_p]
@@ -329,7 +352,9 @@ class ParsedReads:
         self._buf = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, np.uint8)
         self._p = C.POINTER(_Reads)()
         if lib.td_reads_parse(self._buf.ctypes.data, len(self._buf), int(n_threads), C.byref(self._p)) != 0:
-            raise TdError("td_reads_parse failed")
+            self._p = None
+            lib.td_io_last_error.restype = C.c_char_p
+            raise TdError(lib.td_io_last_error().decode() or "td_reads_parse failed")
         r = self._p.contents
         self.n = int(r.n_reads)
         self.offs = np.ctypeslib.as_array(r.offs, shape=(self.n + 1,)).copy()
@@ -520,3 +545,87 @@ class PinnedArray:
             self.free()
         except Exception:
             pass
+
+
+def shard_bounds(n_reads, world, rank):
+    """td_shard_bounds: run_pHMM's contiguous split (barcode_hmm.c:1911-1922); no GPU needed."""
+    lib = load_library()
+    lo, hi = C.c_int64(), C.c_int64()
+    lib.td_shard_bounds(int(n_reads), int(world), int(rank), C.byref(lo), C.byref(hi))
+    return int(lo.value), int(hi.value)
+
+
+def count_outcomes(res, lens=None):
+    """td_count_outcomes: the device counters restated on the host from per-read results; no GPU needed."""
+    lib = load_library()
+    res = np.ascontiguousarray(res, RESULT_DTYPE)
+    c = np.zeros(NUM_COUNTERS, np.int64)
+    ln = None if lens is None else np.ascontiguousarray(lens, np.int32)
+    lib.td_count_outcomes(res.ctypes.data, ln.ctypes.data if ln is not None else None, len(res), c.ctypes.data)
+    return c
+
+
+class TagdustMulti:
+    """Several GPUs driven from one process (include/tagdust_multi.h)."""
+
+    def __init__(self, devices):
+        self.lib = load_library()
+        d = np.ascontiguousarray(devices, np.int32)
+        h = C.c_void_p()
+        if self.lib.td_multi_create(d.ctypes.data, len(d), C.byref(h)) != 0:
+            raise TdError(self.lib.td_multi_last_error(None).decode())
+        self.h = h
+        self._keep = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise TdError(self.lib.td_multi_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.td_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_model(self, md):
+        d, keep = make_model_desc(md)
+        self._keep = keep
+        self._chk(self.lib.td_multi_model_upload(self.h, C.byref(d)))
+
+    def set_params(self, threshold, minlen=16, dust=100):
+        self._chk(self.lib.td_multi_set_params(self.h, float(threshold), int(minlen), int(dust)))
+
+    def set_artifacts(self, string=None, s_index=None, filter_error=2, n_threads=1):
+        if string is None:
+            self._chk(self.lib.td_multi_set_artifacts(self.h, None, None, 0, 0, 1))
+            return
+        a = np.ascontiguousarray(string, np.uint8)
+        ix = np.ascontiguousarray(s_index, np.int32)
+        self._chk(self.lib.td_multi_set_artifacts(self.h, a.ctypes.data, ix.ctypes.data, len(ix) - 1, int(filter_error), int(n_threads)))
+
+    def decode(self, bases, offs, mode=MODE_GET_LABEL, labels=True, seq=True, ascii=False):
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offs = np.ascontiguousarray(offs, np.int64)
+        n = len(offs) - 1
+        res = np.zeros(n, RESULT_DTYPE)
+        lab = np.zeros(int(offs[-1]) + n, np.int8) if labels else None
+        sq = np.zeros(int(offs[-1]), np.uint8) if seq else None
+        self._chk(self.lib.td_multi_decode(self.h, bases.ctypes.data, 1 if ascii else 0, offs.ctypes.data, n, int(mode), res.ctypes.data,
+                                           lab.ctypes.data if labels else None, sq.ctypes.data if seq else None))
+        return res, lab, sq
+
+    def counts(self):
+        c = np.zeros(NUM_COUNTERS, np.int64)
+        self._chk(self.lib.td_multi_counts(self.h, c.ctypes.data))
+        return c
+
+    def counts_reset(self):
+        self._chk(self.lib.td_multi_counts_reset(self.h))
+
+    def uses_rccl(self):
+        return bool(self.lib.td_multi_uses_rccl(self.h))

@@ -2,29 +2,20 @@
 
 The analogue of run_pHMM()'s thread split (src/barcode_hmm.c:1911-1922): interval = n / world, rank r takes
 [r*interval, (r+1)*interval), the last rank takes the remainder.  Per-read results need no exchange; only the
-8 outcome + 256 per-barcode counters (barcode_hmm.c:354-384) are summed over ranks."""
+8 outcome + 256 per-barcode counters (barcode_hmm.c:354-384) are summed over ranks.  Both helpers are the library's own
+host-side C functions (include/tagdust_multi.h: td_shard_bounds, td_count_outcomes), the ones td_multi_decode uses."""
 import numpy as np
 
-from .lib import NUM_COUNTERS
+from .lib import shard_bounds, count_outcomes as _count_outcomes, RESULT_DTYPE  # noqa: F401
 
 
-def shard_bounds(n_reads, world, rank):
-    interval = n_reads // world
-    lo = rank * interval
-    hi = n_reads if rank == world - 1 else (rank + 1) * interval
-    return lo, hi
-
-
-def count_outcomes(read_type, barcode):
-    """Host restatement of the device counters (td_counts_get): slot = outcome code, then barcode & 0xFF bins."""
-    c = np.zeros(NUM_COUNTERS, np.int64)
-    rt = np.asarray(read_type)
-    for code in range(8):
-        c[code] = int((rt == code).sum())
-    bc = np.asarray(barcode)
-    ok = (rt == 0) & (bc >= 0)
-    c[8:] = np.bincount(bc[ok] & 0xFF, minlength=256)
-    return c
+def count_outcomes(read_type, barcode, lens=None):
+    """Host restatement of the device counters: slot = read_type & 7 (an artifact hit is (sequence << 8) | 5), then
+    barcode & 0xFF bins of the extracted reads."""
+    res = np.zeros(len(read_type), RESULT_DTYPE)
+    res["read_type"] = read_type
+    res["barcode"] = barcode
+    return _count_outcomes(res, lens)
 
 
 def allreduce_counts(counts, dist, device=None):

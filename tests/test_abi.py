@@ -23,7 +23,7 @@ def library():
 def test_header_symbols_all_exported(library):
     declared = set()
     for name, want in (("tagdust_hip.h", tdlib.ABI_SYMBOLS), ("tagdust_model.h", tdlib.MODEL_ABI_SYMBOLS),
-                       ("tagdust_io.h", tdlib.IO_ABI_SYMBOLS)):
+                       ("tagdust_io.h", tdlib.IO_ABI_SYMBOLS), ("tagdust_multi.h", tdlib.MULTI_ABI_SYMBOLS)):
         hdr = open(os.path.join(REPO, "include", name)).read()
         hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
         found = set(re.findall(r"\b(td_[a-z_0-9]+)\s*\(", hdr))

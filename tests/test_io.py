@@ -153,6 +153,25 @@ def test_whole_pipeline_without_the_reference(tmp_path, name):
         assert got[k] == want[k], k
 
 
+def test_quality_line_must_match_the_sequence_length():
+    """A FASTQ record whose quality line is shorter than its sequence (e.g. a file cut off mid-record) is an error, as in the
+    reference (io.c:1776-1781, "Length of sequence and base qualities differ") -- never a writer reading past the line."""
+    good = b"@r1\nACGTACGT\n+\nIIIIIIII\n@r2\nACGT\n+\nIIII\n"
+    pr = tdlib.ParsedReads(good, 1)
+    assert pr.n == 2
+    pr.close()
+    for bad in (b"@r1\nACGTACGT\n+\nIIIIIIII\n@r2\nACGTACGT\n+\nIII",      # cut off inside the last quality line
+                b"@r1\nACGTACGT\n+\nIIII\n@r2\nACGT\n+\nIIII\n",          # short quality in the middle
+                b"@r1\nACGT\n+\nIIIIII\n"):                                  # quality longer than the sequence
+        with pytest.raises(tdlib.TdError, match="base qualities"):
+            tdlib.ParsedReads(bad, 1)
+    # a large multi-threaded parse with one bad record somewhere
+    rec = b"@x\n" + b"ACGT" * 25 + b"\n+\n" + b"I" * 100 + b"\n"
+    text = rec * 30000 + b"@bad\nACGTAC\n+\nIII\n" + rec * 30000
+    with pytest.raises(tdlib.TdError, match="bad"):
+        tdlib.ParsedReads(text, 4)
+
+
 def test_fasta_parse_matches_reference_read_fasta():
     """td_fasta_parse against what the reference's get_fasta()/read_fasta() made of the same file (fixture
     artifacts_b_r: mixed case, CRLF line ends, a blank in the header)."""
