@@ -140,61 +140,80 @@ def load_model():
     return {k: z[k] for k in z.files}
 
 
+def _write_fastq(path, reads):
+    n, L = reads.shape
+    rec = np.empty((n, 2 * L + 16), np.uint8)          # "@r0000000\n" + seq + "\n+\n" + qual + "\n"
+    names = np.char.zfill(np.arange(n).astype("U7"), 7)
+    rec[:, :10] = np.frombuffer(("".join("@r%s\n" % x for x in names)).encode(), np.uint8).reshape(n, 10)
+    rec[:, 10:10 + L] = np.frombuffer(b"ACGTN", np.uint8)[reads]
+    rec[:, 10 + L:13 + L] = np.frombuffer(b"\n+\n", np.uint8)
+    rec[:, 13 + L:13 + 2 * L] = ord("I")
+    rec[:, 13 + 2 * L] = ord("\n")
+    rec[:, :14 + 2 * L].tofile(path)
+
+
 def cpu_baseline(model, n_sample, seed):
-    """The CPU oracle (oracle/td_oracle.c, the pinned restatement of the reference's pthread path) timed on
-    this box's host cores on a bounded sample of the same workload.  Checker/baseline only."""
+    """The CPU path timed on this box's host cores on a bounded sample of the same workload, label phase only, same
+    threshold as the GPU run, with all cores of the box's share and with one thread:
+      kind "reference": the reference's own run_pHMM(MODE_GET_LABEL) (oracle/_ref/ref_time: ref_time.c linked against the
+        unmodified reference sources; reads in memory, no calibration, no file output, and without the controller's
+        per-read model rebuild of SURVEY.md quirk Q7, which is not part of the label phase) -- when the snapshot carries it;
+      kind "port": the oracle (oracle/td_oracle.c, the pinned restatement), always reported beside it.
+    Checker / baseline only: nothing here is on the product path."""
+    import subprocess
+    import tempfile
     from oracle import pyoracle
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(cores, int(os.environ.get("TD_CPU_THREADS", "16")))  # a one-GPU box's CPU share is 16 cores
-    reads = synth_batch(n_sample, seed)
-    offs = (np.arange(n_sample + 1, dtype=np.int64) * READ_LEN)
+    L = READ_LEN
+    thr = float(model["threshold"])
+    reads = synth_batch(n_sample, seed).reshape(n_sample, L)
     om = pyoracle.OracleModel(model)
-    pyoracle.label_batch(om, reads[:256].reshape(-1), offs[:257], float(model["threshold"]), 16, 100, cores)  # warm
-    t0 = time.perf_counter()
-    pyoracle.label_batch(om, reads.reshape(-1), offs, float(model["threshold"]), 16, 100, cores)
-    dt = time.perf_counter() - t0
-    out = {"value": n_sample / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-           "sample": "%d reads of the same synthetic workload, oracle/td_oracle.c with %d pthreads, %.1f s wall" % (n_sample, cores, dt)}
-    ref = reference_cli_baseline(reads[:min(n_sample, 20000)], cores)
-    if ref:
-        out["reference_binary"] = ref
-    return out
 
-
-def reference_cli_baseline(reads, cores):
-    """The reference itself (oracle/_ref/tagdust, built by `make -C oracle ref` in the build container and carried to
-    the GPU box with the snapshot), whole job on a bounded sample: FASTQ in, -t <cores>, demultiplexed FASTQ out.
-    -Q skips the threshold calibration prologue.  Reported beside the port; None when the binary is
-    absent or the workload is not config 3."""
-    import subprocess
-    import tempfile
-    exe = os.path.join(REPO, "oracle", "_ref", "tagdust")
-    if not os.path.exists(exe) or _ACTIVE["fixture"] != "c3_b6_s_r_p":
-        return None
-    n, L = reads.shape
-    with tempfile.TemporaryDirectory() as tmp:
-        rec = np.empty((n, 2 * L + 16), np.uint8)          # "@r0000000\n" + seq + "\n+\n" + qual + "\n"
-        names = np.char.zfill(np.arange(n).astype("U7"), 7)
-        head = np.frombuffer(("".join("@r%s\n" % x for x in names)).encode(), np.uint8).reshape(n, 10)
-        rec[:, :10] = head
-        rec[:, 10:10 + L] = np.frombuffer(b"ACGTN", np.uint8)[reads]
-        rec[:, 10 + L:13 + L] = np.frombuffer(b"\n+\n", np.uint8)
-        rec[:, 13 + L:13 + 2 * L] = ord("I")
-        rec[:, 13 + 2 * L] = ord("\n")
-        fq = os.path.join(tmp, "in.fq")
-        rec[:, :14 + 2 * L].tofile(fq)
-        cmd = [exe, "-t", str(cores), "-Q", "20", "-1", "B:" + ",".join(BARCODES), "-2", "S:" + SPACER, "-3", "R:N",
-               "-4", "P:" + ADAPTER, fq, "-o", os.path.join(tmp, "out")]
+    def port(n, threads):
+        offs = np.arange(n + 1, dtype=np.int64) * L
+        pyoracle.label_batch(om, reads[:256].reshape(-1), offs[:257], thr, 16, 100, threads)  # warm
         t0 = time.perf_counter()
-        try:
-            p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
-        except Exception:
-            return None
+        pyoracle.label_batch(om, reads[:n].reshape(-1), offs, thr, 16, 100, threads)
         dt = time.perf_counter() - t0
-        if p.returncode != 0:
-            return None
-    return {"value": n / dt, "unit": "reads/s", "cores": cores, "kind": "reference",
-            "sample": "%d reads, oracle/_ref/tagdust -t %d -Q 20 (no calibration), FASTQ in and out, %.1f s wall" % (n, cores, dt)}
+        return {"value": n / dt, "unit": "reads/s", "cores": threads, "reads": n, "seconds": dt}
+
+    n1 = max(min(n_sample // 12, 20000), 256)
+    out_port = {"kind": "port", "what": "oracle/td_oracle.c (pinned restatement of the reference's path), pthreads over contiguous ranges",
+                "all_cores": port(n_sample, cores), "one_thread": port(n1, 1)}
+    exe = os.path.join(REPO, "oracle", "_ref", "ref_time")
+    out_ref = None
+    if os.path.exists(exe) and _ACTIVE["fixture"] == "c3_b6_s_r_p":
+        def ref(n, threads):
+            with tempfile.TemporaryDirectory() as tmp:
+                fq = os.path.join(tmp, "in.fq")
+                _write_fastq(fq, reads[:n])
+                cmd = [exe, repr(thr), "-t", str(threads), "-1", "B:" + ",".join(BARCODES), "-2", "S:" + SPACER, "-3", "R:N",
+                       "-4", "P:" + ADAPTER, fq, "-o", os.path.join(tmp, "out")]
+                p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+                if p.returncode != 0:
+                    return None
+                d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+                return {"value": d["reads"] / d["seconds"], "unit": "reads/s", "cores": threads, "reads": d["reads"],
+                        "seconds": d["seconds"], "extracted": d["extracted"]}
+        try:
+            ra, r1 = ref(n_sample, cores), ref(n1, 1)
+            if ra and r1:
+                out_ref = {"kind": "reference", "what": "the reference's run_pHMM(MODE_GET_LABEL) on reads in memory (oracle/_ref/ref_time), "
+                           "calibrated threshold given, no calibration / file I/O / per-read model rebuild (quirk Q7) in the timed region",
+                           "all_cores": ra, "one_thread": r1}
+        except Exception as e:   # the baseline must not take the bench down
+            out_ref = None
+            sys.stderr.write("bench.py: reference baseline failed: %s\n" % e)
+    head = out_ref or out_port
+    out = {"value": head["all_cores"]["value"], "unit": "reads/s", "cores": cores, "kind": head["kind"],
+           "sample": "%d reads of the same synthetic workload (label phase only, threshold %.4f as on the GPU), %s, %.1f s wall; "
+                     "-t 1 on %d reads: %.0f reads/s" % (head["all_cores"]["reads"], thr, head["what"], head["all_cores"]["seconds"],
+                                                          head["one_thread"]["reads"], head["one_thread"]["value"]),
+           "one_thread": head["one_thread"], "port": out_port}
+    if out_ref:
+        out["reference"] = out_ref
+    return out
 
 
 class _DevCounters:
@@ -315,7 +334,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=1 << 20, help="reads per step per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=60000, help="reads in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=200000, help="reads in the CPU baseline sample (0 = skip)")
     ap.add_argument("--check", type=int, default=2048, help="reads verified against the oracle before timing (0 = skip)")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS), help="development only; the bench line is c3")
     ap.add_argument("--specialize", type=int, default=1, help="0 = generic ahead-of-time kernel")
@@ -323,6 +342,11 @@ def main():
     ap.add_argument("--pinned", type=int, default=0, help="1 = the caller's buffers are page-locked (td_host_alloc): no host copies at all")
     ap.add_argument("--extras", type=int, default=1, help="0 = skip the extra measurements (kernel only, pinned I/O, configs 2 and 5)")
     args = ap.parse_args()
+    # Rank 0 prints ONE JSON line on stdout: everything else that writes to file descriptor 1 while this runs (RCCL's version
+    # banner, for one) is sent to stderr, and the line goes to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     # host threads the library may use for its copies between pageable caller memory and pinned staging: two per GPU,
     # so that eight ranks on one node stay far inside the host's cores
     os.environ.setdefault("TD_HOST_THREADS", "2")
@@ -460,7 +484,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(model, args.cpu_sample, seed=77)
         elif args.cpu_sample:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
