@@ -130,6 +130,13 @@ int64_t td_spec_source(const td_model_desc* model, char* buf, int64_t cap);
  * read_type = (1-based sequence index << 8) | 5.  n_seq = 0 switches the filter off. */
 int td_set_artifacts(td_ctx* ctx, const uint8_t* string, const int32_t* s_index, int32_t n_seq,
                      int32_t filter_error, int32_t n_threads);
+/* -start / -end (param->matchstart, param->matchend; -1, -1 = none): do_probability_estimation / do_label_thread then
+ * decode seq + matchstart for matchend - matchstart bases (src/barcode_hmm.c:2195-2210, :2290-2313).  With a window set,
+ * batches uploaded afterwards are cut to it on the device and TD_MODE_GET_PROB / TD_MODE_ARCH_COMP score the window.
+ * The reference reads past the end of a read shorter than matchend (undefined); here such a read is scored on what it
+ * has inside the window.  TD_MODE_GET_LABEL is refused while a window is set: what extract_reads / make_extracted_read
+ * do with window labels on whole-read positions stays with the reference's own code. */
+int td_set_window(td_ctx* ctx, int32_t matchstart, int32_t matchend);
 /* The batches this context gets from now on are reads [first_read, first_read + n) of a batch of total_reads reads that is
  * shared out over several contexts (tagdust_multi.h): the artifact filter's thread ranges are then taken over the whole
  * batch, so that every read is scored by the routine the reference would use for it.  total_reads = 0: a batch is whole. */
@@ -175,6 +182,16 @@ int td_wait(td_ctx* ctx, int64_t ticket);
 /* Page-locked host memory for batch inputs / outputs (NULL on failure). */
 void* td_host_alloc(size_t bytes);
 void  td_host_free(void* p);
+
+/* ---- architecture comparison (TD_MODE_ARCH_COMP for many models at once) ----
+ * test_architectures() hands run_pHMM every candidate model bag and the first batch of reads (src/test_architectures.c:
+ * 182-184); each thread then runs backward() alone for every candidate over its reads (do_arch_comparison,
+ * src/barcode_hmm.c:2111-2148).  Here: the reads are staged once, every candidate's tables go to HBM, and ONE launch of
+ * the generic kernel (no per-candidate compile) scores all of them -- the launch's second grid dimension is the
+ * candidate.  b_scores[k * n_reads + i] = backward score of read i under models[k] (mb->b_score), in the caller's
+ * order.  The context's own model, parameters and counters are untouched; its resident batch is replaced. */
+int td_arch_scores(td_ctx* ctx, const td_model_desc* const* models, int32_t n_models, const uint8_t* codes,
+                   const int64_t* offs, int64_t n_reads, float* b_scores /* [n_models][n_reads] */);
 
 /* ---- counters (the reference's serial outcome counting, barcode_hmm.c:354-384, done on device) ---- */
 int td_counts_reset(td_ctx* ctx);

@@ -87,11 +87,12 @@ int   td_estimate_threshold(td_ctx* ctx, const td_arch* arch, const td_seq_stats
 
 /* ---- architecture selection, test_architectures() src/test_architectures.c:20-289 ----
  * Every candidate gets its own sequence statistics and model (error rate e, indel frequency d); the first <= 100 000
- * reads are scored with backward() alone (TD_MODE_ARCH_COMP, generic kernel: no per-candidate compile) and the
+ * reads are scored with backward() alone for all candidates in one launch (td_arch_scores: generic kernel, no per-candidate
+ * compile, reads staged once) and the
  * per-candidate float sums are formed over the reference's n_threads contiguous ranges in read order, then over the
  * ranges (barcode_hmm.c:2111-2148, :1995-2016) -- the float result depends on that order.  posterior[k] is the
- * normalised probability the reference logs as "Confidence"; *best the index it selects.  Replaces the context's model
- * and resident batch (the last candidate's); the "specialize" option is restored to what it was. */
+ * normalised probability the reference logs as "Confidence"; *best the index it selects.  The context's model and
+ * options are untouched; its resident batch is replaced. */
 int   td_compare_architectures(td_ctx* ctx, const td_arch* const* archs, int32_t n_arch, const uint8_t* codes,
                                const int64_t* offs, int64_t n_reads, float sequencer_error_rate, float indel_frequency,
                                int32_t n_threads, float* posterior, int32_t* best);

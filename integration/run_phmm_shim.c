@@ -42,7 +42,17 @@ static uint64_t fnv(uint64_t h, const void* p, size_t n)
 	return h;
 }
 
-static int upload_model(struct model_bag* mb, struct parameters* param, int with_types)
+/* struct model_bag -> td_model_desc; the tables are malloc'ed, flat_free() releases them */
+typedef struct flat_model { td_model_desc d; void* mem[11]; } flat_model;
+
+static void flat_free(flat_model* fm)
+{
+	int k;
+	for (k = 0; k < 11; k++) free(fm->mem[k]);
+	memset(fm, 0, sizeof *fm);
+}
+
+static void flatten_model(struct model_bag* mb, struct parameters* param, int with_types, flat_model* fm)
 {
 	const int S = mb->num_models, H = mb->total_hmm_num;
 	int C = 0, j, f, g, k;
@@ -82,61 +92,69 @@ static int upload_model(struct model_bag* mb, struct parameters* param, int with
 	for (j = 0; j < H; j++)
 		for (k = 0; k < H; k++) A[j * H + k] = mb->transition_matrix[j][k];
 
-	td_model_desc d;
-	memset(&d, 0, sizeof d);
-	d.S = S; d.H = H; d.C = C; d.avg_len = mb->average_raw_length;
-	for (k = 0; k < 5; k++) d.bg[k] = mb->model[0]->background_nuc_frequency[k];
-	d.n_hmm = n_hmm; d.n_col = n_col; d.skip = skip; d.seg_type = type; d.finger_len = finger;
-	d.trans = trans; d.eM = eM; d.eI = eI; d.sM = sM; d.sI = sI; d.label = mb->label; d.A = A;
+	td_model_desc* d = &fm->d;
+	memset(fm, 0, sizeof *fm);
+	d->S = S; d->H = H; d->C = C; d->avg_len = mb->average_raw_length;
+	for (k = 0; k < 5; k++) d->bg[k] = mb->model[0]->background_nuc_frequency[k];
+	d->n_hmm = n_hmm; d->n_col = n_col; d->skip = skip; d->seg_type = type; d->finger_len = finger;
+	d->trans = trans; d->eM = eM; d->eI = eI; d->sM = sM; d->sI = sI; d->label = mb->label; d->A = A;
+	void* mem[11] = { n_hmm, n_col, finger, skip, type, trans, eM, eI, sM, sI, A };
+	memcpy(fm->mem, mem, sizeof mem);
+}
 
+static int upload_model(struct model_bag* mb, struct parameters* param, int with_types)
+{
+	flat_model fm;
+	flatten_model(mb, param, with_types, &fm);
+	const td_model_desc* d = &fm.d;
+	const int S = d->S, H = d->H, C = d->C;
 	uint64_t key = 1469598103934665603ULL;
-	key = fnv(key, &d.S, 16); key = fnv(key, d.bg, 20);
-	key = fnv(key, n_hmm, 4 * S); key = fnv(key, n_col, 4 * S); key = fnv(key, skip, 4 * S); key = fnv(key, type, S);
-	key = fnv(key, trans, 36 * C); key = fnv(key, eM, 20 * C); key = fnv(key, eI, 20 * C);
-	key = fnv(key, sM, 4 * C); key = fnv(key, sI, 4 * C); key = fnv(key, mb->label, 4 * H); key = fnv(key, A, 4 * H * H);
+	key = fnv(key, &d->S, 16); key = fnv(key, d->bg, 20);
+	key = fnv(key, d->n_hmm, 4 * S); key = fnv(key, d->n_col, 4 * S); key = fnv(key, d->skip, 4 * S); key = fnv(key, d->seg_type, S);
+	key = fnv(key, d->trans, 36 * C); key = fnv(key, d->eM, 20 * C); key = fnv(key, d->eI, 20 * C);
+	key = fnv(key, d->sM, 4 * C); key = fnv(key, d->sI, 4 * C); key = fnv(key, d->label, 4 * H); key = fnv(key, d->A, 4 * H * H);
 	int rc = TD_OK;
 	if (key != g_model_key) {
-		rc = td_model_upload(g_ctx, &d);
+		rc = td_model_upload(g_ctx, d);
 		if (rc == TD_OK) g_model_key = key;
 	}
-	free(n_hmm); free(n_col); free(finger); free(skip); free(type);
-	free(trans); free(eM); free(eI); free(sM); free(sI); free(A);
+	flat_free(&fm);
 	return rc;
 }
 
 /* MODE_ARCH_COMP (do_arch_comparison, barcode_hmm.c:2111-2148 + the merge at :1995-2016): every candidate model
  * scores every read with backward(); arch_posterior[j] is the float sum of b_score, accumulated per thread range
  * in read order and then over threads -- the summation order (hence the float result) depends on -t, so it is
- * reproduced here on the host from the per-read b_scores the GPU returns.  The many short-lived candidate models
- * use the generic kernel (no per-model compile). */
+ * reproduced here on the host from the per-read b_scores the GPU returns.  All candidates are scored by ONE launch
+ * (td_arch_scores: the reads are staged once, the candidates' tables sit in HBM, generic kernel, no per-model compile). */
 static int arch_comparison(struct arch_bag* ab, struct read_info** ri, struct parameters* param, int numseq)
 {
 	int i, j, t, rc = kslOK;
 	const int T = param->num_threads > 0 ? param->num_threads : 1;
 	const int interval = (int)(numseq / T);
+	const int NA = ab->num_arch;
 	int64_t* offs = malloc(sizeof(int64_t) * ((size_t)numseq + 1));
 	offs[0] = 0;
 	for (i = 0; i < numseq; i++) offs[i + 1] = offs[i] + ri[i]->len;
 	uint8_t* codes = malloc((size_t)offs[numseq] + 1);
 	for (i = 0; i < numseq; i++) memcpy(codes + offs[i], ri[i]->seq, (size_t)ri[i]->len);
-	td_read_result* res = malloc(sizeof(td_read_result) * (size_t)numseq);
+	float* b = malloc(sizeof(float) * (size_t)numseq * (size_t)NA);
+	flat_model* fm = calloc((size_t)NA, sizeof(flat_model));
+	const td_model_desc** descs = malloc(sizeof(td_model_desc*) * (size_t)NA);
+	for (j = 0; j < NA; j++) { flatten_model(ab->archs[j], param, 0, &fm[j]); descs[j] = &fm[j].d; }
 
-	if (td_set_option(g_ctx, "specialize", 0) != TD_OK) rc = kslFAIL;
-	for (j = 0; j < ab->num_arch && rc == kslOK; j++) {
-		g_model_key = 0;
-		if (upload_model(ab->archs[j], param, 0) != TD_OK || td_batch_upload(g_ctx, codes, offs, numseq) != TD_OK ||
-		    td_run(g_ctx, TD_MODE_ARCH_COMP) != TD_OK || td_batch_download(g_ctx, res, NULL, NULL) != TD_OK) {
-			rc = kslFAIL;
-			break;
-		}
+	if (td_set_window(g_ctx, -1, -1) != TD_OK || td_arch_scores(g_ctx, descs, NA, codes, offs, numseq, b) != TD_OK) rc = kslFAIL;
+	for (j = 0; j < NA && rc == kslOK; j++) {
+		const float* bj = b + (size_t)j * (size_t)numseq;
 		for (t = 0; t < T; t++) {
 			const int start = t * interval, end = (t == T - 1) ? numseq : (t + 1) * interval;
 			float partial = prob2scaledprob(1.0);            /* thread_data[t].ab->arch_posterior[i], :1938 */
-			for (i = start; i < end; i++) partial += res[i].b_score;
+			for (i = start; i < end; i++) partial += bj[i];
 			ab->arch_posterior[j] += partial;                /* :2003 */
 		}
 	}
-	g_model_key = 0;
+	for (j = 0; j < NA; j++) flat_free(&fm[j]);
+	free(fm); free(descs);
 	if (rc == kslOK) {                                       /* :2009-2016 */
 		float sum = ab->arch_posterior[0];
 		for (i = 1; i < ab->num_arch; i++) sum = logsum(sum, ab->arch_posterior[i]);
@@ -144,7 +162,7 @@ static int arch_comparison(struct arch_bag* ab, struct read_info** ri, struct pa
 	} else {
 		fprintf(stderr, "tagdust_hip: %s\n", td_last_error(g_ctx));
 	}
-	free(offs); free(codes); free(res);
+	free(offs); free(codes); free(b);
 	return rc;
 }
 
@@ -153,10 +171,17 @@ int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, s
 {
 	int i, k, status = kslOK;
 
-	/* not on the GPU path: training modes, -start/-end windows */
+	const int windowed = param->matchstart != -1 || param->matchend != -1;
+	/* not on the GPU path: training modes; -start/-end windows except for the scores (MODE_GET_PROB) of reads that reach
+	   matchend -- the reference reads past the end of a shorter read there, and in label mode applies window labels to
+	   whole-read positions (barcode_hmm.c:3325-3356), which stays with its own code */
 	if ((mode != MODE_GET_LABEL && mode != MODE_GET_PROB && mode != MODE_ARCH_COMP) || (mode == MODE_ARCH_COMP && !ab) ||
-	    param->matchstart != -1 || param->matchend != -1)
+	    (windowed && mode != MODE_GET_PROB))
 		return ref_run_pHMM(ab, mb, ri, param, reference_fasta, numseq, mode);
+	if (windowed) {
+		if (param->matchstart < 0 || param->matchend <= param->matchstart) return ref_run_pHMM(ab, mb, ri, param, reference_fasta, numseq, mode);
+		for (i = 0; i < numseq; i++) if (ri[i]->len < param->matchend) return ref_run_pHMM(ab, mb, ri, param, reference_fasta, numseq, mode);
+	}
 	if (numseq <= 0) return kslOK;
 
 	if (!g_ctx && td_ctx_create(0, &g_ctx) != TD_OK) {
@@ -167,6 +192,7 @@ int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, s
 	if (td_set_option(g_ctx, "specialize", 1) != TD_OK) goto ERROR;
 	if (upload_model(mb, param, 1) != TD_OK) goto ERROR;
 	if (td_set_params(g_ctx, param->confidence_threshold, param->minlen, param->dust) != TD_OK) goto ERROR;
+	if (td_set_window(g_ctx, windowed ? param->matchstart : -1, windowed ? param->matchend : -1) != TD_OK) goto ERROR;
 	/* -ref: match_to_reference (barcode_hmm.c:2349-2351) moves to the device; it only runs in label mode */
 	if (mode == MODE_GET_LABEL && reference_fasta && param->reference_fasta) {
 		if (td_set_artifacts(g_ctx, reference_fasta->string, reference_fasta->s_index, reference_fasta->numseq,

@@ -23,6 +23,7 @@
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t td_launch_decode(const TdKernelArgs* ka, hipStream_t stream);   // library-internal
 extern "C" __attribute__((visibility("hidden"))) int td_kernel_block_threads(void);
+extern "C" __attribute__((visibility("hidden"))) hipError_t td_launch_decode_multi(const TdKernelArgs* d_args, int n_models, int max_slots, hipStream_t stream);
 
 static float g_logsum[TD_LOGSUM_SIZE];
 static bool g_logsum_ready = false;
@@ -48,6 +49,7 @@ struct TdSlot {
 	int is_ascii = 0, mode = 0;
 	bool sorted = false;      // device order differs from the caller's (reads of several lengths)
 	bool staged = false;      // inputs are packed on the device: td_run may launch
+	bool windowed = false;    // packed through a -start / -end window
 	bool ran = false, finished = false;
 	float last_ms = -1.0f;
 	int64_t ticket = 0;       // td_submit: 0 = free
@@ -126,6 +128,7 @@ struct td_ctx {
 	uint8_t* d_art_text = nullptr; int32_t* d_art_index = nullptr;
 	int32_t art_n = 0, art_fe = 0, art_threads = 1;
 	int64_t win_first = 0, win_total = 0;   // td_set_batch_window
+	int32_t match_start = 0, match_len = 0;  // td_set_window (-start / -end); match_len = 0: whole reads
 	// batches: slot 0 is the resident batch of the synchronous calls; td_submit rotates over pipeline_depth slots
 	TdSlot slots[TD_MAX_PIPELINE];
 	int pipeline_depth = 3, next_slot = 0, last_slot = 0;
@@ -335,10 +338,26 @@ static bool spec_lsum_range_ok(const td_ctx* c, int lmax)
 	return 6.0 * (double)c->m_maxabs * ((double)lmax + 2.0) < limit;
 }
 
-extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
+// The model as the generic kernel reads it from HBM: header, columns, per-HMM info, label predecessor lists.
+struct DevModel {
+	TdModelHeader h{};
+	TdModelHeader* d_hdr = nullptr;
+	TdCol* d_cols = nullptr;
+	uint32_t* d_hinfo = nullptr;
+	int32_t* d_pred_off = nullptr;
+	int32_t* d_pred_idx = nullptr;
+};
+
+static void free_dev_model(DevModel& d)
 {
-	if (!c || !m) return fail(c, "td_model_upload: NULL argument");
-	HIPCHK(c, hipSetDevice(c->device));
+	void* p[] = { d.d_hdr, d.d_cols, d.d_hinfo, d.d_pred_off, d.d_pred_idx };
+	for (void* q : p) if (q) (void)hipFree(q);
+	d = DevModel();
+}
+
+// validate a description and put its tables on the device (synchronous copies)
+static int build_dev_model(td_ctx* c, const td_model_desc* m, DevModel& out)
+{
 	if (m->S < 1 || m->S > TD_MAX_SEGMENTS) return fail(c, "td_model_upload: %d segments (1..%d supported)", m->S, TD_MAX_SEGMENTS);
 	if (m->H < 1 || m->H > TD_MAX_HMMS) return fail(c, "td_model_upload: %d HMMs (1..%d supported)", m->H, TD_MAX_HMMS);
 	if (!m->n_hmm || !m->n_col || !m->skip || !m->seg_type || !m->finger_len || !m->trans || !m->eM || !m->eI ||
@@ -398,24 +417,37 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 	poff[m->H] = (int32_t)pidx.size();
 	if (pidx.empty()) pidx.push_back(0);
 
+	DevModel d;
+	d.h = h;
+	bool ok = hipMalloc((void**)&d.d_hdr, sizeof h) == hipSuccess && hipMalloc((void**)&d.d_cols, sizeof(TdCol) * cols.size()) == hipSuccess &&
+	          hipMalloc((void**)&d.d_hinfo, sizeof(uint32_t) * hinfo.size()) == hipSuccess &&
+	          hipMalloc((void**)&d.d_pred_off, sizeof(int32_t) * poff.size()) == hipSuccess &&
+	          hipMalloc((void**)&d.d_pred_idx, sizeof(int32_t) * pidx.size()) == hipSuccess &&
+	          hipMemcpy(d.d_hdr, &h, sizeof h, hipMemcpyHostToDevice) == hipSuccess &&
+	          hipMemcpy(d.d_cols, cols.data(), sizeof(TdCol) * cols.size(), hipMemcpyHostToDevice) == hipSuccess &&
+	          hipMemcpy(d.d_hinfo, hinfo.data(), sizeof(uint32_t) * hinfo.size(), hipMemcpyHostToDevice) == hipSuccess &&
+	          hipMemcpy(d.d_pred_off, poff.data(), sizeof(int32_t) * poff.size(), hipMemcpyHostToDevice) == hipSuccess &&
+	          hipMemcpy(d.d_pred_idx, pidx.data(), sizeof(int32_t) * pidx.size(), hipMemcpyHostToDevice) == hipSuccess;
+	if (!ok) { free_dev_model(d); return fail(c, "td_model_upload: device tables: %s", hipGetErrorString(hipGetLastError())); }
+	out = d;
+	return TD_OK;
+}
+
+extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
+{
+	if (!c || !m) return fail(c, "td_model_upload: NULL argument");
+	HIPCHK(c, hipSetDevice(c->device));
+	DevModel dm;
+	if (build_dev_model(c, m, dm) != TD_OK) return TD_FAIL;
+	const TdModelHeader h = dm.h;
 	// from here on the context holds no usable model / batch until every step below has succeeded
 	c->have_model = false;
 	for (int k = 0; k < TD_MAX_PIPELINE; k++) { c->slots[k].staged = false; c->slots[k].ran = false; }   // batches are staged per model
-	if (tickets_outstanding(c)) return fail(c, "td_model_upload: td_submit tickets are outstanding (td_wait them first)");
+	if (tickets_outstanding(c)) { free_dev_model(dm); return fail(c, "td_model_upload: td_submit tickets are outstanding (td_wait them first)"); }
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	void* old[] = { c->d_hdr, c->d_cols, c->d_hinfo, c->d_pred_off, c->d_pred_idx };
-	for (void* p : old) if (p) HIPCHK(c, hipFree(p));
-	c->d_hdr = nullptr; c->d_cols = nullptr; c->d_hinfo = nullptr; c->d_pred_off = nullptr; c->d_pred_idx = nullptr;
-	HIPCHK(c, hipMalloc((void**)&c->d_hdr, sizeof h));
-	HIPCHK(c, hipMalloc((void**)&c->d_cols, sizeof(TdCol) * cols.size()));
-	HIPCHK(c, hipMalloc((void**)&c->d_hinfo, sizeof(uint32_t) * hinfo.size()));
-	HIPCHK(c, hipMalloc((void**)&c->d_pred_off, sizeof(int32_t) * poff.size()));
-	HIPCHK(c, hipMalloc((void**)&c->d_pred_idx, sizeof(int32_t) * pidx.size()));
-	HIPCHK(c, hipMemcpy(c->d_hdr, &h, sizeof h, hipMemcpyHostToDevice));
-	HIPCHK(c, hipMemcpy(c->d_cols, cols.data(), sizeof(TdCol) * cols.size(), hipMemcpyHostToDevice));
-	HIPCHK(c, hipMemcpy(c->d_hinfo, hinfo.data(), sizeof(uint32_t) * hinfo.size(), hipMemcpyHostToDevice));
-	HIPCHK(c, hipMemcpy(c->d_pred_off, poff.data(), sizeof(int32_t) * poff.size(), hipMemcpyHostToDevice));
-	HIPCHK(c, hipMemcpy(c->d_pred_idx, pidx.data(), sizeof(int32_t) * pidx.size(), hipMemcpyHostToDevice));
+	for (void* p : old) if (p) (void)hipFree(p);
+	c->d_hdr = dm.d_hdr; c->d_cols = dm.d_cols; c->d_hinfo = dm.d_hinfo; c->d_pred_off = dm.d_pred_off; c->d_pred_idx = dm.d_pred_idx;
 	c->hdr = h;
 	c->label.assign(m->label, m->label + m->H);
 	c->m_n_hmm.assign(m->n_hmm, m->n_hmm + m->S);
@@ -504,6 +536,15 @@ extern "C" int td_set_artifacts(td_ctx* c, const uint8_t* string, const int32_t*
 	if (bytes) HIPCHK(c, hipMemcpy(c->d_art_text, string, bytes, hipMemcpyHostToDevice));
 	HIPCHK(c, hipMemcpy(c->d_art_index, s_index, sizeof(int32_t) * ((size_t)n_seq + 1), hipMemcpyHostToDevice));
 	c->art_n = n_seq; c->art_fe = filter_error; c->art_threads = n_threads;
+	return TD_OK;
+}
+
+extern "C" int td_set_window(td_ctx* c, int32_t matchstart, int32_t matchend)
+{
+	if (!c) return TD_FAIL;
+	if (matchstart == -1 && matchend == -1) { c->match_start = 0; c->match_len = 0; return TD_OK; }
+	if (matchstart < 0 || matchend <= matchstart) return fail(c, "td_set_window: need 0 <= matchstart < matchend (or -1, -1 for none)");
+	c->match_start = matchstart; c->match_len = matchend - matchstart;
 	return TD_OK;
 }
 
@@ -659,11 +700,11 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 
 // Reads -> device, sorted and packed.  Copies go on `up` (the compute stream itself for the synchronous calls); the
 // kernels on the compute stream wait for them through ev_up.
-static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, const int64_t* offs, int64_t n, hipStream_t up)
+static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, const int64_t* offs, int64_t n, hipStream_t up, bool with_workspace = true)
 {
 	s.staged = false; s.ran = false; s.finished = false;
 	s.n_reads = 0; s.n_tiles = 0;
-	if (!c->have_model) return fail(c, "td_batch_upload: no model uploaded");
+	if (with_workspace && !c->have_model) return fail(c, "td_batch_upload: no model uploaded");
 	if (!offs || n < 0 || (!bases && n > 0 && offs[n] > offs[0])) return fail(c, "td_batch_upload: bad arguments");
 	if (n > 0x7fffffffLL - TD_WAVE) return fail(c, "td_batch_upload: %lld reads in one batch", (long long)n);
 	HIPCHK(c, hipSetDevice(c->device));
@@ -678,8 +719,13 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 		const int64_t l = offs[i + 1] - offs[i];
 		s.h_offs[i + 1] = offs[i + 1] - base;
 		if (l < 0 || l > 100000) { bad = i; break; }
-		if (l > lmax) lmax = (int)l;
-		if (l < lmin) lmin = (int)l;
+		int lw = (int)l;
+		if (c->match_len > 0) {   // the decode kernels see the window only
+			const int e = lw < c->match_start + c->match_len ? lw : c->match_start + c->match_len;
+			lw = e > c->match_start ? e - c->match_start : 0;
+		}
+		if (lw > lmax) lmax = lw;
+		if (lw < lmin) lmin = lw;
 	}
 	if (bad >= 0) return fail(c, "td_batch_upload: read %lld has length %lld", (long long)bad, (long long)(offs[bad + 1] - offs[bad]));
 	const int64_t n_bases = n > 0 ? offs[n] - base : 0;
@@ -702,7 +748,7 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 			return TD_FAIL;
 	}
 	s.lmax = lmax; s.nw2 = nw2; s.nw1 = nw1; s.n_tiles = (int32_t)n_tiles;
-	if (ensure_workspace(c, s) != TD_OK) { s.n_tiles = 0; return TD_FAIL; }
+	if (with_workspace && ensure_workspace(c, s) != TD_OK) { s.n_tiles = 0; return TD_FAIL; }
 	s.n_tiles = 0;
 
 	// host -> device: page-locked caller memory goes straight to the DMA engine, anything else through pinned staging
@@ -719,12 +765,14 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 		HIPCHK(c, hipStreamWaitEvent(c->stream, s.ev_up, 0));
 	}
 	if (sorted)
-		HIPCHK(c, td_stage_sort(s.d_offs, n, lmax, s.d_read_at, s.d_keys, s.d_keys + n, s.d_vals, s.d_sort_tmp, sort_tmp, c->stream));
+		HIPCHK(c, td_stage_sort(s.d_offs, n, lmax, c->match_start, c->match_len, s.d_read_at, s.d_keys, s.d_keys + n, s.d_vals, s.d_sort_tmp, sort_tmp, c->stream));
 	TdStageBatch& b = s.sb;
 	b = TdStageBatch{};
 	b.raw = s.d_raw; b.offs = s.d_offs; b.n_reads = n; b.is_ascii = is_ascii;
 	b.n_tiles = (int32_t)n_tiles; b.lmax = lmax; b.nw2 = nw2; b.nw1 = nw1;
 	b.read_at = sorted ? s.d_read_at : nullptr;
+	b.win_start = c->match_start; b.win_len = c->match_len;
+	s.windowed = c->match_len > 0;
 	b.packed = s.d_packed; b.lens = s.d_lens; b.art_left = s.d_art_left;
 	b.out_soa = s.d_out; b.soa_stride = ol.soa_stride;
 	b.keep = (const uint32_t*)(s.d_out + ol.keep); b.labels = (const int8_t*)(s.d_out + ol.labels);
@@ -741,6 +789,8 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 	if (!c->have_model) return fail(c, "td_run: no model uploaded");
 	if (mode != TD_MODE_GET_LABEL && mode != TD_MODE_GET_PROB && mode != TD_MODE_ARCH_COMP) return fail(c, "td_run: unsupported mode %d", mode);
 	if (!s.staged) return fail(c, "td_run: no batch resident (td_batch_upload failed or was not called)");
+	if (s.windowed && mode == TD_MODE_GET_LABEL)
+		return fail(c, "td_run: TD_MODE_GET_LABEL through a -start/-end window is not on the device path (only the scores are defined there)");
 	HIPCHK(c, hipSetDevice(c->device));
 	s.mode = mode; s.finished = false;
 	if (s.n_tiles == 0) { s.ran = true; s.last_ms = 0.0f; return TD_OK; }
@@ -812,6 +862,7 @@ static int slot_issue_copies(td_ctx* c, TdSlot& s, hipStream_t down)
 static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* labels, uint8_t* seq_out, bool deferred)
 {
 	if (!s.ran) return fail(c, "td_batch_download: td_run has not been called on this batch");
+	if (s.windowed && (labels || seq_out)) return fail(c, "td_batch_download: labels / sequences are not available through a -start/-end window");
 	s.u_res = res; s.u_labels = labels; s.u_seq = seq_out;
 	s.res_direct = s.lab_direct = s.seq_direct = false;
 	s.copies_deferred = deferred;
@@ -941,6 +992,108 @@ extern "C" int td_wait(td_ctx* c, int64_t ticket)
 		}
 	}
 	return fail(c, "td_wait: no batch with ticket %lld is in flight", (long long)ticket);
+}
+
+// ---- architecture comparison: every candidate model over one batch, backward() only, one launch ----
+extern "C" int td_arch_scores(td_ctx* c, const td_model_desc* const* models, int32_t n_models, const uint8_t* codes,
+                              const int64_t* offs, int64_t n_reads, float* b_scores)
+{
+	if (!c || !models || n_models < 1 || !offs || !b_scores || n_reads < 0) return fail(c, "td_arch_scores: bad arguments");
+	if (tickets_outstanding(c)) return fail(c, "td_arch_scores: td_submit tickets are outstanding (td_wait them first)");
+	HIPCHK(c, hipSetDevice(c->device));
+	TdSlot& s = c->slots[0];
+	// the reads are staged (sorted by length, packed) once; no model of the context is involved
+	if (slot_stage(c, s, codes, 0, offs, n_reads, c->stream, false) != TD_OK) return TD_FAIL;
+	s.staged = false;                      // not a batch td_run could use: it has no workspace geometry
+	if (s.n_tiles == 0) return TD_OK;
+	const int wpb = td_kernel_block_threads() / TD_WAVE;
+	const int64_t n_lanes = (int64_t)s.n_tiles * TD_WAVE;
+	const int64_t wave_budget = (int64_t)c->n_cu * 2 * wpb;
+	std::vector<DevModel> dm((size_t)n_models);
+	int rc = TD_OK;
+	float* d_b = nullptr;
+	TdKernelArgs* d_args = nullptr;
+	std::vector<float> h_b;
+	std::vector<int32_t> h_read_at;
+	auto cleanup = [&]() {
+		for (auto& d : dm) free_dev_model(d);
+		if (d_b) (void)hipFree(d_b);
+		if (d_args) (void)hipFree(d_args);
+	};
+	if (hipMalloc((void**)&d_b, sizeof(float) * (size_t)(n_lanes * n_models)) != hipSuccess ||
+	    hipMalloc((void**)&d_args, sizeof(TdKernelArgs) * (size_t)n_models) != hipSuccess) { cleanup(); return fail(c, "td_arch_scores: out of device memory"); }
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { cleanup(); return fail(c, "td_arch_scores: hipMemGetInfo failed"); }
+	const int64_t ws_budget = (int64_t)((double)(free_b + c->cap_ws) * 0.85);
+	// candidates go in chunks whose workspaces fit side by side; within a chunk the chip's wave slots are shared out evenly
+	std::vector<TdKernelArgs> args((size_t)n_models);
+	int k0 = 0;
+	while (k0 < n_models && rc == TD_OK) {
+		int k1 = k0;
+		int64_t ws_total = 0;
+		std::vector<int64_t> ws_off;
+		int max_slots = 0;
+		// first guess: all remaining candidates in one launch
+		int chunk = n_models - k0;
+		for (;;) {
+			int64_t per = wave_budget / chunk / wpb * wpb;
+			if (per < wpb) per = wpb;
+			int64_t cap = ((int64_t)s.n_tiles + wpb - 1) / wpb * wpb;
+			if (per > cap) per = cap;
+			ws_total = 0; ws_off.clear(); max_slots = (int)per;
+			bool fits = true;
+			for (int k = k0; k < k0 + chunk; k++) {
+				if (!dm[(size_t)k].d_hdr && build_dev_model(c, models[k], dm[(size_t)k]) != TD_OK) { cleanup(); return TD_FAIL; }
+				TdWsLayout lay;
+				make_layout(lay, dm[(size_t)k].h.S, dm[(size_t)k].h.H, dm[(size_t)k].h.C, s.lmax, dm[(size_t)k].h.max_ncol);
+				ws_off.push_back(ws_total);
+				ws_total += align256(per * lay.slot_bytes);
+				if (ws_total > ws_budget) { fits = false; break; }
+			}
+			if (fits) { k1 = k0 + chunk; break; }
+			if (chunk == 1) { cleanup(); return fail(c, "td_arch_scores: the workspace of candidate %d does not fit in HBM", k0); }
+			chunk = (chunk + 1) / 2;
+		}
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		if (ensure(c, &c->d_ws, &c->cap_ws, (size_t)ws_total) != TD_OK) { cleanup(); return TD_FAIL; }
+		for (int k = k0; k < k1; k++) {
+			const DevModel& d = dm[(size_t)k];
+			TdKernelArgs ka{};
+			ka.hdr = d.d_hdr; ka.cols = d.d_cols; ka.hinfo = d.d_hinfo; ka.pred_off = d.d_pred_off; ka.pred_idx = d.d_pred_idx;
+			ka.logsum = c->d_logsum; ka.packed = s.d_packed; ka.lens = s.d_lens;
+			ka.n_tiles = s.n_tiles; ka.n_slots = max_slots; ka.lmax = s.lmax; ka.nw2 = s.nw2; ka.nw1 = s.nw1;
+			ka.mode = TD_MODE_ARCH_COMP; ka.threshold = 0.0f; ka.minlen = c->minlen; ka.dust = 0; ka.want_labels = 0;
+			ka.out_b = d_b + (int64_t)k * n_lanes;       // backward-only mode writes nothing else
+			ka.counters = c->d_counters;
+			ka.ws = c->d_ws + ws_off[(size_t)(k - k0)];
+			make_layout(ka.lay, d.h.S, d.h.H, d.h.C, s.lmax, d.h.max_ncol);
+			args[(size_t)k] = ka;
+		}
+		if (hipMemcpyAsync(d_args + k0, args.data() + k0, sizeof(TdKernelArgs) * (size_t)(k1 - k0), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+		    td_launch_decode_multi(d_args + k0, k1 - k0, max_slots, c->stream) != hipSuccess ||
+		    hipStreamSynchronize(c->stream) != hipSuccess) {   // args.data() must outlive the copy
+			rc = fail(c, "td_arch_scores: launch failed: %s", hipGetErrorString(hipGetLastError()));
+		}
+		k0 = k1;
+	}
+	if (rc == TD_OK) {
+		h_b.resize((size_t)(n_lanes * n_models));
+		if (hipMemcpy(h_b.data(), d_b, sizeof(float) * h_b.size(), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(c, "td_arch_scores: download failed");
+		if (rc == TD_OK && s.sorted) {
+			h_read_at.resize((size_t)n_reads);
+			if (hipMemcpy(h_read_at.data(), s.d_read_at, sizeof(int32_t) * (size_t)n_reads, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(c, "td_arch_scores: download failed");
+		}
+	}
+	if (rc == TD_OK) {
+		for (int k = 0; k < n_models; k++) {
+			const float* src = h_b.data() + (int64_t)k * n_lanes;
+			float* dst = b_scores + (int64_t)k * n_reads;
+			if (s.sorted) for (int64_t p = 0; p < n_reads; p++) dst[h_read_at[(size_t)p]] = src[p];
+			else memcpy(dst, src, sizeof(float) * (size_t)n_reads);
+		}
+	}
+	cleanup();
+	return rc;
 }
 
 extern "C" void* td_host_alloc(size_t bytes)

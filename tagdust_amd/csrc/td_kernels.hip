@@ -439,7 +439,7 @@ __device__ __forceinline__ void fwd_segment_reg(const WaveCtx& w, const TdSeg sg
 // ---------------------------------------------------------------------------------------------------------
 // the kernel: a persistent wave walks tiles slot, slot + n_slots, ...
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TD_BLOCK, 2) void td_decode_kernel(const TdKernelArgs ka)
+__device__ __forceinline__ void decode_body(const TdKernelArgs& ka, const int block_x)
 {
 	const LdsTable T{};
 	for (int k = threadIdx.x; k < TD_LOGSUM_LIVE + 4; k += TD_BLOCK) g_T[k] = (k < TD_LOGSUM_LIVE) ? ka.logsum[k] : 0.0f;
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(TD_BLOCK, 2) void td_decode_kernel(const TdKernelAr
 
 	const int lane = threadIdx.x & (TD_WAVE - 1);
 	const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int slot = blockIdx.x * TD_WAVES_PER_BLOCK + wave_in_block;
+	const int slot = block_x * TD_WAVES_PER_BLOCK + wave_in_block;
 	if (slot >= ka.n_slots) return;
 
 	const TdModelHeader TD_CONST& hd = *as_const(ka.hdr);
@@ -777,6 +777,26 @@ __global__ __launch_bounds__(TD_BLOCK, 2) void td_decode_kernel(const TdKernelAr
 			if (read_type == OUT_SUCCESS && barcode >= 0) atomicAdd(&ka.counters[N_OUTCOME_SLOTS + (barcode & 0xFF)], 1ull);
 		}
 	}
+}
+
+__global__ __launch_bounds__(TD_BLOCK, 2) void td_decode_kernel(const TdKernelArgs ka)
+{
+	decode_body(ka, blockIdx.x);
+}
+
+// Many models over one batch in one launch (architecture comparison, test_architectures.c:182-184 calls run_pHMM with all
+// candidate model bags): blockIdx.y selects the model's argument block -- its own tables, workspace region and output.
+__global__ __launch_bounds__(TD_BLOCK, 2) void td_decode_multi_kernel(const TdKernelArgs* __restrict__ args)
+{
+	const TdKernelArgs ka = args[blockIdx.y];
+	decode_body(ka, blockIdx.x);
+}
+
+extern "C" __attribute__((visibility("hidden"))) hipError_t td_launch_decode_multi(const TdKernelArgs* d_args, int n_models, int max_slots, hipStream_t stream)
+{
+	const int blocks = (max_slots + TD_WAVES_PER_BLOCK - 1) / TD_WAVES_PER_BLOCK;
+	hipLaunchKernelGGL(td_decode_multi_kernel, dim3(blocks, n_models), dim3(TD_BLOCK), 0, stream, d_args);
+	return hipGetLastError();
 }
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t td_launch_decode(const TdKernelArgs* ka, hipStream_t stream)

@@ -805,30 +805,31 @@ extern "C" int td_compare_architectures(td_ctx* ctx, const td_arch* const* archs
 	// test_architectures() sets num_query = 100 000 (:38-42): statistics then scan batches of 100 000 reads until more than
 	// 1 000 000 were seen (1 100 000 reads), and the candidates are scored on the first batch only (:182-184)
 	const int64_t n_score = n_reads < 100000 ? n_reads : 100000;
-	std::vector<td_read_result> res((size_t)n_score);
-	// the many short-lived candidate models run the generic kernel (no per-model compile); the caller's setting comes back
-	int32_t specialize_was = 1;
-	if (td_get_option(ctx, "specialize", &specialize_was) != TD_OK) return TD_FAIL;
-	int rc = td_set_option(ctx, "specialize", 0);
+	// every candidate's own sequence statistics and model (test_architectures.c:60-170), then all of them over the first
+	// batch in one launch of the generic kernel (td_arch_scores: no per-candidate compile, reads staged once)
+	std::vector<td_model_tables*> tabs((size_t)n_arch, nullptr);
+	std::vector<const td_model_desc*> descs((size_t)n_arch, nullptr);
+	int rc = TD_OK;
 	for (int k = 0; k < n_arch && rc == TD_OK; k++) {
 		td_seq_stats st;
-		td_model_tables* m = nullptr;
-		if (sequence_stats_limit(archs[k], codes, offs, n_reads, &st, 1100000) != TD_OK || td_model_build(archs[k], &st, e, d, &m) != TD_OK) { rc = TD_FAIL; break; }
-		if (td_model_upload(ctx, &m->desc) != TD_OK || td_batch_upload(ctx, codes, offs, n_score) != TD_OK ||
-		    td_run(ctx, TD_MODE_ARCH_COMP) != TD_OK || td_batch_download(ctx, res.data(), nullptr, nullptr) != TD_OK) rc = TD_FAIL;
-		td_model_tables_free(m);
-		if (rc != TD_OK) break;
+		if (sequence_stats_limit(archs[k], codes, offs, n_reads, &st, 1100000) != TD_OK || td_model_build(archs[k], &st, e, d, &tabs[(size_t)k]) != TD_OK) rc = TD_FAIL;
+		else descs[(size_t)k] = &tabs[(size_t)k]->desc;
+	}
+	std::vector<float> b((size_t)n_arch * (size_t)n_score);
+	if (rc == TD_OK && td_arch_scores(ctx, descs.data(), n_arch, codes, offs, n_score, b.data()) != TD_OK) rc = TD_FAIL;
+	for (td_model_tables* t : tabs) td_model_tables_free(t);
+	for (int k = 0; k < n_arch && rc == TD_OK; k++) {
+		const float* bk = b.data() + (size_t)k * (size_t)n_score;
 		float total = p2sp(1.0);                                      // ab->arch_posterior[i] = prob2scaledprob(1.0), test_architectures.c:164
 		const int64_t interval = n_score / n_threads;                  // barcode_hmm.c:1911
 		for (int t = 0; t < n_threads; t++) {
 			const int64_t lo = t * interval, hi = (t == n_threads - 1) ? n_score : (t + 1) * interval;
 			float partial = p2sp(1.0);                                 // :1935
-			for (int64_t i = lo; i < hi; i++) partial += res[(size_t)i].b_score; // do_arch_comparison :2135
+			for (int64_t i = lo; i < hi; i++) partial += bk[i];       // do_arch_comparison :2135
 			total += partial;                                          // :2003
 		}
 		posterior[k] = total;
 	}
-	(void)td_set_option(ctx, "specialize", specialize_was);
 	if (rc != TD_OK) return TD_FAIL;
 	if (n_arch > 1) {
 		float sum = posterior[0];                                      // barcode_hmm.c:2009-2016

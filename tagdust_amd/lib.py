@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "td_ctx_create", "td_ctx_destroy", "td_last_error", "td_logsum_table", "td_model_upload", "td_set_params",
     "td_batch_upload", "td_batch_upload_ascii", "td_run", "td_sync", "td_batch_download", "td_counts_reset",
     "td_counts_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_batch_info", "td_set_option", "td_get_option", "td_set_artifacts", "td_spec_source",
-    "td_submit", "td_wait", "td_host_alloc", "td_host_free", "td_set_batch_window",
+    "td_submit", "td_wait", "td_host_alloc", "td_host_free", "td_set_batch_window", "td_set_window", "td_arch_scores",
 ]
 MULTI_ABI_SYMBOLS = ["td_shard_bounds", "td_count_outcomes", "td_multi_create", "td_multi_destroy", "td_multi_last_error",
                      "td_multi_size", "td_multi_ctx", "td_multi_model_upload", "td_multi_set_params", "td_multi_set_artifacts",
@@ -115,6 +115,8 @@ def load_library():
     lib.td_host_free.argtypes = [C.c_void_p]
     lib.td_host_free.restype = None
     lib.td_set_batch_window.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+    lib.td_set_window.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.td_arch_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.td_shard_bounds.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.td_shard_bounds.restype = None
     lib.td_count_outcomes.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
@@ -464,6 +466,9 @@ class TagdustHip:
     def set_params(self, threshold, minlen=16, dust=100):
         self._chk(self.lib.td_set_params(self.h, float(threshold), int(minlen), int(dust)))
 
+    def set_window(self, matchstart=-1, matchend=-1):
+        self._chk(self.lib.td_set_window(self.h, int(matchstart), int(matchend)))
+
     def upload_batch(self, codes, offs):
         codes = np.ascontiguousarray(codes, np.uint8)
         self.offs = np.ascontiguousarray(offs, np.int64)
@@ -501,6 +506,21 @@ class TagdustHip:
 
     def wait(self, ticket):
         self._chk(self.lib.td_wait(self.h, int(ticket)))
+
+    def arch_scores(self, models, codes, offs):
+        """td_arch_scores: backward score of every read under every candidate model, one launch; float32 [n_models, n]."""
+        descs, keep = [], []
+        for md in models:
+            d, k = make_model_desc(md)
+            descs.append(d)
+            keep.append(k)
+        ptrs = (C.c_void_p * len(descs))(*[C.addressof(d) for d in descs])
+        codes = np.ascontiguousarray(codes, np.uint8)
+        offs = np.ascontiguousarray(offs, np.int64)
+        n = len(offs) - 1
+        out = np.zeros((len(descs), n), np.float32)
+        self._chk(self.lib.td_arch_scores(self.h, ptrs, len(descs), codes.ctypes.data, offs.ctypes.data, n, out.ctypes.data))
+        return out
 
     def counts_reset(self):
         self._chk(self.lib.td_counts_reset(self.h))

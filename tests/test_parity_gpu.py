@@ -343,6 +343,83 @@ def test_long_reads_switch_to_clamped_logsum(monkeypatch):
     assert np.array_equal(seq0, seq1) and np.array_equal(seq0, g["seq_after"])
 
 
+def test_arch_scores_one_launch_for_all_candidates():
+    """td_arch_scores: several candidate models over one (ragged) batch in a single launch of the generic kernel must give,
+    per model, exactly the b_scores of a TD_MODE_ARCH_COMP run with that model alone -- and of the oracle."""
+    from oracle import pyoracle
+    from tagdust_amd import TagdustHip, MODE_ARCH_COMP
+    names = ["c2_b4_r", "umi_f_s_r", "o_b_s_r", "scen2_endloss", "c3_b6_s_r_p", "b_intp_g_r", "c5_b96_f_r_p"]
+    models = [load_golden(n_) for n_ in names]
+    g = load_golden("c2_indel_varlen")
+    seq, offs = g["seq"], g["offs"]
+    c = TagdustHip(0)
+    try:
+        got = c.arch_scores(models, seq, offs)
+        assert got.shape == (len(models), int(g["n_reads"]))
+        c.set_option("specialize", 0)
+        for k, m in enumerate(models):
+            c.upload_model(m)
+            c.set_params(0.0, 16, 100)
+            c.upload_batch(seq, offs)
+            c.run(MODE_ARCH_COMP)
+            res, _, _ = c.download(labels=False, seq=False)
+            assert np.array_equal(_bits(got[k]), _bits(res["b_score"])), names[k]
+        ores = pyoracle.label_batch(pyoracle.OracleModel(models[0]), seq, offs, 0.0, 16, 100, 4)[0]
+        assert np.array_equal(_bits(got[0]), _bits(ores["b_score"]))
+        # many copies of one candidate: more models than fit the chip's wave slots at full width
+        many = c.arch_scores([models[1]] * 40, seq, offs)
+        assert all(np.array_equal(_bits(many[k]), _bits(got[1])) for k in range(40))
+    finally:
+        c.close()
+
+
+def test_start_end_window_scores(ctx):
+    """-start / -end: do_probability_estimation decodes seq + matchstart for matchend - matchstart bases
+    (barcode_hmm.c:2195-2210).  With td_set_window the device cuts the reads itself; the scores must equal the oracle's on
+    the cut reads, bit for bit, for uniform and ragged batches (a read that ends inside the window is scored on what it
+    has there); label mode is refused."""
+    from oracle import pyoracle
+    from tagdust_amd import MODE_GET_PROB, MODE_ARCH_COMP, TdError
+    g = load_golden("c2_b4_r")
+    om = pyoracle.OracleModel(g)
+    rng = np.random.RandomState(21)
+    n = 500
+    for ragged in (False, True):
+        lens = rng.randint(40, 101, n) if ragged else np.full(n, 100)
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        seq = rng.randint(0, 4, int(offs[-1])).astype(np.uint8)
+        src = g["offs"]
+        for i in range(0, n, 2):
+            k = i % int(g["n_reads"])
+            s_ = g["seq"][src[k]:src[k + 1]][:lens[i] - 3]
+            seq[offs[i] + 3:offs[i] + 3 + len(s_)] = s_                     # the architecture starts at base 3
+        start, end = 3, 63
+        cut = [seq[offs[i] + start:offs[i] + min(lens[i], end)] for i in range(n)]
+        coffs = np.concatenate([[0], np.cumsum([len(c_) for c_ in cut])]).astype(np.int64)
+        ores, _, _ = pyoracle.label_batch(om, np.concatenate(cut), coffs, float(g["threshold"]), 16, 100, 8)
+        ctx.upload_model(g)
+        ctx.set_params(float(g["threshold"]), 16, 100)
+        ctx.set_window(start, end)
+        try:
+            ctx.upload_batch(seq, offs)
+            ctx.run(MODE_GET_PROB)
+            res, _, _ = ctx.download(labels=False, seq=False)
+            for k in ("b_score", "f_score", "r_score", "bar_prob"):
+                assert np.array_equal(_bits(res[k]), _bits(ores[k])), (k, ragged)
+            assert np.allclose(res["mapq"], ores["Q"], rtol=0, atol=Q_TOL)
+            ctx.run(MODE_ARCH_COMP)
+            res, _, _ = ctx.download(labels=False, seq=False)
+            assert np.array_equal(_bits(res["b_score"]), _bits(ores["b_score"]))
+            with pytest.raises(TdError, match="window"):
+                ctx.run()
+        finally:
+            ctx.set_window(-1, -1)
+    ctx.upload_batch(g["seq"], g["offs"])          # back to whole reads
+    ctx.run()
+    res, labels, _ = ctx.download()
+    assert np.array_equal(labels, g["labels"])
+
+
 def test_logsum_selfcheck_falls_back_to_clamped_form(monkeypatch, capfd):
     """Every load of a compiled kernel runs lsum() over the operand pairs that matter (-inf operands, gaps around the 15.7
     cut, huge gaps) against the reference's formula; a failing clamp-free form must be replaced by the clamped one, with a
