@@ -7,6 +7,7 @@
 
 int td_spec_group_size(int n_hmm, int n_col, int target_override);
 int td_spec_pure_last(const td_model_desc* m, int j, int col_off);
+int td_spec_drop_m(const td_model_desc* m, int j, int col_off);      /* 1: the column before the pure last column spills I_backward only */
 int td_spec_rt_prefix(const td_model_desc* m, int j, int col_off, int8_t* base, float* hi, float* lo, float* nv);
 int td_spec_block_threads(void);
 int td_spec_min_waves(void);
