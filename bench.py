@@ -46,7 +46,9 @@ _CODE = {"A": 0, "C": 1, "G": 2, "T": 3}
 WORKLOADS = {
     "c3": dict(fixture="c3_b6_s_r_p", read_len=150, barcodes=BARCODES, umi=0, spacer=SPACER, adapter=ADAPTER, name=WORKLOAD),
     "c2": dict(fixture="c2_b4_r", read_len=100, barcodes=["TGCT", "AAAA", "AACC", "AAGG", "AATT", "ACAC", "ACCA", "ACGT"],
-               umi=0, spacer="", adapter="", name="config2: 100bp reads, arch -1 B:<8 of EDITTAG_4nt_ed_2> -2 R:N (BASELINE.json configs[1])"),
+               umi=0, spacer="", adapter="", simreads=True,
+               name="config2: simreads -sim_barnum 8 -sim_readlen 96 -sim_random_frac 0.1 -sim_error_rate 0.02 (4 nt barcode + 96 nt read; the "
+                    "random tenth is 96 nt), arch -1 B:<8 of EDITTAG_4nt_ed_2> -2 R:N (BASELINE.json configs[1])"),
     "c5": dict(fixture="c5_b96_f_r_p", read_len=150, barcodes=None, umi=8, spacer="", adapter=ADAPTER,
                name="config5: 150bp reads, arch -1 B:<96 of EDITTAG_6nt_ed_3> -2 F:NNNNNNNN -3 R:N -4 P:AGATCGGAAGAGC (BASELINE.json configs[4])"),
 }
@@ -56,8 +58,25 @@ _ACTIVE = dict(WORKLOADS["c3"])
 def select_workload(name):
     """Make `name` (c2 / c3 / c5) the workload synth_batch() and load_model() work on."""
     global READ_LEN
+    _ACTIVE.clear()
     _ACTIVE.update(WORKLOADS[name])
     READ_LEN = _ACTIVE["read_len"]
+
+
+def synth_host_batch(n, seed):
+    """One host batch of the active workload: (base codes uint8, offsets int64).  Configs the reference's simreads can emit
+    (config 2) come from the library's restatement of it (td_simreads: byte-identical to `simreads <tags> -seed <seed>
+    -sim_barnum 8 -sim_readlen 96 -sim_readlen_mod 0 -sim_numseq <n> -sim_endloss 0 -sim_random_frac 0.1 -sim_error_rate
+    0.02`), parsed by the library's FASTQ parser; the others from the generators below."""
+    if _ACTIVE.get("simreads"):
+        from tagdust_amd import lib as tdlib
+        text = tdlib.simreads(_ACTIVE["barcodes"], seed=seed, barnum=len(_ACTIVE["barcodes"]), readlen=READ_LEN - len(_ACTIVE["barcodes"][0]),
+                              numseq=n, random_frac=0.1, error_rate=0.02)
+        pr = tdlib.ParsedReads(text, 0)
+        codes, offs = pr.codes.copy(), pr.offs.copy()
+        pr.close()
+        return codes, offs
+    return synth_batch(n, seed).reshape(-1), np.arange(n + 1, dtype=np.int64) * READ_LEN
 
 
 def synth_batch(n, seed, read_len=None, random_frac=0.1, sub=0.02):
@@ -224,14 +243,15 @@ class _DevCounters:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
 
 
-def run_pipelined(ctx, host_batches, offs, outs, steps, depth):
+def run_pipelined(ctx, host_batches, outs, steps, depth):
     """`steps` host-to-host batches through td_submit / td_wait, `depth` in flight; returns per-batch kernel ms."""
     tickets, k_ms = [], []
     trace = [] if os.environ.get("TD_BENCH_TRACE") else None
     for k in range(steps):
         o = outs[k % len(outs)]
         t0 = time.perf_counter()
-        tickets.append(ctx.submit(host_batches[k % len(host_batches)], offs, res=o[0], seq_out=o[1]))
+        hb = host_batches[k % len(host_batches)]
+        tickets.append(ctx.submit(hb[0], hb[1], res=o[0], seq_out=o[1][:len(hb[0])]))
         t1 = time.perf_counter()
         if len(tickets) >= depth:
             ctx.wait(tickets.pop(0))
@@ -257,8 +277,6 @@ def measure_workload(name, n, steps, warmup, dev_index, specialize=1, depth=2, p
     ctx.set_option("pipeline_depth", depth)
     ctx.upload_model(model)
     ctx.set_params(float(model["threshold"]), 16, 100)
-    L = READ_LEN
-    offs = np.arange(n + 1, dtype=np.int64) * L
     rank = int(os.environ.get("RANK", "0"))
     n_host = 3            # distinct host batches, handed over in turn: every step uploads reads the device does not hold
     pins = []
@@ -272,21 +290,24 @@ def measure_workload(name, n, steps, warmup, dev_index, specialize=1, depth=2, p
 
     host_batches = []
     for b in range(n_host):
-        a = host_array((n * L,), np.uint8)
-        a[:] = synth_batch(n, seed=1000 + 17 * rank + b).reshape(-1)
-        host_batches.append(a)
-    outs = [(host_array((n,), RESULT_DTYPE), host_array((n * L,), np.uint8)) for _ in range(depth + 1)]
+        codes, boffs = synth_host_batch(n, seed=1000 + 17 * rank + b)
+        a = host_array((len(codes),), np.uint8)
+        a[:] = codes
+        host_batches.append((a, boffs))
+    max_bases = max(len(h[0]) for h in host_batches)
+    outs = [(host_array((n,), RESULT_DTYPE), host_array((max_bases,), np.uint8)) for _ in range(depth + 1)]
 
     if check and rank == 0:   # correctness spot-check against the oracle (outside the timed region)
         from oracle import pyoracle
         k = min(check, n)
         om = pyoracle.OracleModel(model)
-        ores, olab, oseq = pyoracle.label_batch(om, host_batches[0][:k * L], offs[:k + 1], float(model["threshold"]), 16, 100,
-                                                min(8, os.cpu_count() or 1))
+        coffs = np.ascontiguousarray(host_batches[0][1][:k + 1])
+        ccodes = np.ascontiguousarray(host_batches[0][0][:int(coffs[-1])])
+        ores, olab, oseq = pyoracle.label_batch(om, ccodes, coffs, float(model["threshold"]), 16, 100, min(8, os.cpu_count() or 1))
         res = np.zeros(k, RESULT_DTYPE)
-        lab = np.zeros(k * (L + 1), np.int8)
-        sq = np.zeros(k * L, np.uint8)
-        ctx.wait(ctx.submit(np.ascontiguousarray(host_batches[0][:k * L]), np.ascontiguousarray(offs[:k + 1]), res=res, labels=lab, seq_out=sq))
+        lab = np.zeros(int(coffs[-1]) + k, np.int8)
+        sq = np.zeros(int(coffs[-1]), np.uint8)
+        ctx.wait(ctx.submit(ccodes, coffs, res=res, labels=lab, seq_out=sq))
         ok = (np.array_equal(lab, olab) and np.array_equal(res["read_type"], ores["read_type"]) and
               np.array_equal(res["barcode"], ores["barcode"]) and np.array_equal(sq, oseq) and
               np.array_equal(res["f_score"].view(np.uint32), ores["f_score"].view(np.uint32)) and
@@ -294,7 +315,7 @@ def measure_workload(name, n, steps, warmup, dev_index, specialize=1, depth=2, p
         if not ok:
             raise SystemExit("bench.py: HIP result differs from the oracle on the %s workload -- refusing to time it" % name)
 
-    run_pipelined(ctx, host_batches, offs, outs, max(warmup, 1), depth)
+    run_pipelined(ctx, host_batches, outs, max(warmup, 1), depth)
     ctx.sync()
     ctx.counts_reset()
     ctx.sync()
@@ -302,13 +323,13 @@ def measure_workload(name, n, steps, warmup, dev_index, specialize=1, depth=2, p
     state = {"k_ms": []}
 
     def go():
-        state["k_ms"] = run_pipelined(ctx, host_batches, offs, outs, steps, depth)
+        state["k_ms"] = run_pipelined(ctx, host_batches, outs, steps, depth)
 
     def kernel_only():
         """The decode kernel alone over a resident batch (round 1's figure), outside the timed region."""
         if not kernel_only_steps:
             return None
-        ctx.upload_batch(host_batches[0], offs)
+        ctx.upload_batch(host_batches[0][0], host_batches[0][1])
         ms = []
         ctx.run(); ctx.sync()
         t0 = time.perf_counter()

@@ -85,6 +85,30 @@ void  td_calibration_free(td_calibration* cal);
 int   td_estimate_threshold(td_ctx* ctx, const td_arch* arch, const td_seq_stats* stats, float indel_frequency,
                             uint32_t seed, int32_t n_reads, int32_t rng, float* threshold);
 
+/* ---- synthetic reads: the reference's simreads (src/simulate_reads.c:28-470, mutate() :480-560) ----
+ * The bench and test inputs of the architectures simreads can emit ([5' linker][barcode] mutated + uniform read +
+ * [3' linker] mutated, optional end loss, a share of fully random reads appended at the end; names "@READ<i>;SEQ:<read>;
+ * RBC:<barcode>;BARNUM:<k>", qualities all 'I') on the same rand() sequence: with rng 0 the C library's (glibc: an inline
+ * copy checked against srand()/rand()), with rng 1 the -DRTEST generator (misc.c:878-887).  The text equals the file
+ * "simreads <tags> -seed S -sim_... -o file" writes, byte for byte.  Free it with td_text_free. */
+typedef struct td_sim_params {
+	uint32_t seed;            /* -seed                                   */
+	int32_t  rng;             /* 0 = rand(), 1 = the RTEST generator      */
+	int32_t  barnum;          /* -sim_barnum (first barnum tags are used) */
+	int32_t  barlen;          /* -sim_barlen (length of the random reads only) */
+	int32_t  readlen;         /* -sim_readlen                             */
+	int32_t  readlen_mod;     /* -sim_readlen_mod                         */
+	int32_t  numseq;          /* -sim_numseq                              */
+	int32_t  end_loss;        /* -sim_endloss                             */
+	float    random_frac;     /* -sim_random_frac                         */
+	float    error_rate;      /* -sim_error_rate                          */
+	float    indel_frac;      /* -sim_InDel_frac                          */
+	const char* seq5;         /* -sim_5seq or NULL                        */
+	const char* seq3;         /* -sim_3seq or NULL                        */
+} td_sim_params;
+int   td_simreads(const td_sim_params* p, const char* const* barcodes, int32_t n_barcodes, char** fastq_out, int64_t* len_out);
+void  td_text_free(char* text);
+
 /* ---- architecture selection, test_architectures() src/test_architectures.c:20-289 ----
  * Every candidate gets its own sequence statistics and model (error rate e, indel frequency d); the first <= 100 000
  * reads are scored with backward() alone for all candidates in one launch (td_arch_scores: generic kernel, no per-candidate

@@ -508,6 +508,12 @@ struct Rng {
 		own = GlibcRand::matches_libc();
 		if (own) g.seed(s); else srand(s);
 	}
+	// a plain rand() (simulate_reads.c draws barcode numbers and lengths with rand() % n)
+	int irand()
+	{
+		if (kind) { next = next * 1103515245u + 12345u; return (int)((unsigned)(next / 65536) % 32768); }
+		return own ? g.next() : rand();
+	}
 	// "(float)rand()/(float)my_rand_max", barcode_hmm.c:2610,2721 (my_rand_max = RAND_MAX, or 32768 under RTEST)
 	long long n_draws = 0;
 	double draw()
@@ -792,6 +798,100 @@ extern "C" int td_estimate_threshold(td_ctx* ctx, const td_arch* a, const td_seq
 	td_calibration_free(cal);
 	return rc;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// simulate_reads.c:28-470 (the reference's simreads): the bench / test inputs of the architectures it can emit
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+char sim_base(Rng& rng)
+{
+	const double r = rng.draw();                              // simulate_reads.c:176-186
+	return r < 0.25 ? 'A' : r < 0.5 ? 'C' : r < 0.75 ? 'G' : 'T';
+}
+
+// mutate(), simulate_reads.c:480-560
+std::string sim_mutate(const td_sim_params* p, const std::string& seq, Rng& rng)
+{
+	std::string out;
+	const int len = (int)seq.size();
+	for (int j = 0; j < len; j++) {
+		double r = rng.draw();
+		if (r <= (double)p->error_rate) {
+			r = rng.draw();
+			if (r <= (double)p->indel_frac) {
+				r = rng.draw();
+				const double cutoff = (j == len - 1) ? 0.0 : 0.5;
+				if (r <= cutoff) { const char n = sim_base(rng); out += seq[(size_t)j]; out += n; }   // insertion; else deletion
+			} else {
+				char n = seq[(size_t)j];
+				while (n == seq[(size_t)j]) n = sim_base(rng);
+				out += n;
+			}
+		} else {
+			out += seq[(size_t)j];
+		}
+	}
+	return out;
+}
+
+} // namespace
+
+extern "C" int td_simreads(const td_sim_params* p, const char* const* barcodes, int32_t n_barcodes, char** fastq_out, int64_t* len_out)
+{
+	if (!p || !fastq_out || !len_out || p->numseq < 0 || p->barnum < 0 || (p->barnum > 0 && (!barcodes || n_barcodes < p->barnum))) return TD_FAIL;
+	if (p->readlen < 0 || p->readlen_mod < 0 || p->end_loss < 0) return TD_FAIL;
+	Rng rng;
+	rng.kind = p->rng;
+	rng.seed(p->seed);                                        // srand(seed), :37
+	std::string out;
+	out.reserve((size_t)p->numseq * (size_t)(2 * (p->readlen + 40) + 64));
+	char num[48];
+	const std::string seq5 = p->seq5 ? p->seq5 : "", seq3 = p->seq3 ? p->seq3 : "";
+	const int n_real = (int)((double)(float)p->numseq * (1.0 - (double)p->random_frac));   // :141
+	for (int i = 0; i < n_real; i++) {
+		std::string tmp = seq5;
+		int used = 0;
+		if (p->barnum) { used = rng.irand() % p->barnum; tmp += barcodes[used]; }              // :155-159
+		std::string sequenced = sim_mutate(p, tmp, rng);
+		int c = p->readlen;
+		if (p->readlen_mod) c = p->readlen - p->readlen_mod + rng.irand() % (p->readlen_mod * 2);   // :169-173
+		std::string read;
+		for (int j = 0; j < c; j++) read += sim_base(rng);
+		sequenced += read;
+		if (p->seq3) sequenced += sim_mutate(p, seq3, rng);                                      // :193-199
+		if (p->end_loss) {                                                                       // :202-219
+			int start = rng.irand() % (p->end_loss * 2);
+			sequenced = start < (int)sequenced.size() ? sequenced.substr((size_t)start) : std::string();
+			start = rng.irand() % (p->end_loss * 2);
+			if (start > 0) sequenced = start < (int)sequenced.size() ? sequenced.substr(0, sequenced.size() - (size_t)start) : std::string();
+		}
+		snprintf(num, sizeof num, "@READ%d;SEQ:", i);
+		out += num; out += read;
+		if (p->barnum) { out += ";RBC:"; out += barcodes[used]; snprintf(num, sizeof num, ";BARNUM:%d", used + 1); out += num; }
+		else out += ";BARNUM:1";
+		out += '\n'; out += sequenced; out += "\n+\n"; out.append(sequenced.size(), 'I'); out += '\n';
+	}
+	// fully random sequences (:259-321): length = linkers + sim_barlen + read length; the end-loss draws are made (and act
+	// on another buffer there), so they are consumed here too
+	const int c = (int)seq5.size() + (int)seq3.size() + p->barlen + p->readlen;
+	for (int i = n_real; i < p->numseq; i++) {
+		std::string s;
+		for (int j = 0; j < c; j++) s += sim_base(rng);
+		if (p->end_loss) { (void)rng.irand(); (void)rng.irand(); }
+		snprintf(num, sizeof num, "@RAND%d;SEQ:NONE;", i);
+		out += num; out += p->barnum ? "RBC:NONE;BARNUM:0" : "BARNUM:0";
+		out += '\n'; out += s; out += "\n+\n"; out.append((size_t)c, 'I'); out += '\n';
+	}
+	char* buf = (char*)malloc(out.size() + 1);
+	if (!buf) return TD_FAIL;
+	memcpy(buf, out.data(), out.size());
+	buf[out.size()] = 0;
+	*fastq_out = buf; *len_out = (int64_t)out.size();
+	return TD_OK;
+}
+
+extern "C" void td_text_free(char* text) { free(text); }
 
 // ---------------------------------------------------------------------------------------------------------
 // architecture selection, test_architectures.c:20-289

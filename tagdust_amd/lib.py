@@ -29,7 +29,7 @@ IO_ABI_SYMBOLS = ["td_io_last_error", "td_reads_parse", "td_reads_free", "td_wri
                   "td_fasta_parse", "td_fasta_free"]
 MODEL_ABI_SYMBOLS = ["td_arch_parse", "td_arch_free", "td_sequence_stats", "td_model_build", "td_model_tables_free",
                      "td_calibration_emit", "td_calibration_select", "td_calibration_free", "td_estimate_threshold",
-                     "td_compare_architectures"]
+                     "td_compare_architectures", "td_simreads", "td_text_free"]
 
 RESULT_DTYPE = np.dtype([
     ("f_score", "<f4"), ("b_score", "<f4"), ("r_score", "<f4"), ("bar_prob", "<f4"), ("mapq", "<f4"),
@@ -649,3 +649,28 @@ class TagdustMulti:
 
     def uses_rccl(self):
         return bool(self.lib.td_multi_uses_rccl(self.h))
+
+
+class _SimParams(C.Structure):
+    _fields_ = [("seed", C.c_uint32), ("rng", C.c_int32), ("barnum", C.c_int32), ("barlen", C.c_int32), ("readlen", C.c_int32),
+                ("readlen_mod", C.c_int32), ("numseq", C.c_int32), ("end_loss", C.c_int32), ("random_frac", C.c_float),
+                ("error_rate", C.c_float), ("indel_frac", C.c_float), ("seq5", C.c_char_p), ("seq3", C.c_char_p)]
+
+
+def simreads(barcodes, seed=42, rng=0, barnum=0, barlen=0, readlen=0, readlen_mod=0, numseq=0, end_loss=0, random_frac=0.0,
+             error_rate=0.0, indel_frac=0.0, seq5=None, seq3=None):
+    """td_simreads: the FASTQ text the reference's simreads writes for these options (bytes)."""
+    lib = load_library()
+    p = _SimParams(int(seed), int(rng), int(barnum), int(barlen), int(readlen), int(readlen_mod), int(numseq), int(end_loss),
+                   float(random_frac), float(error_rate), float(indel_frac), seq5.encode() if seq5 else None, seq3.encode() if seq3 else None)
+    arr = (C.c_char_p * max(len(barcodes), 1))(*[b.encode() for b in barcodes])
+    out, n = C.c_void_p(), C.c_int64()
+    lib.td_simreads.argtypes = [C.POINTER(_SimParams), C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    lib.td_text_free.argtypes = [C.c_void_p]
+    lib.td_text_free.restype = None
+    if lib.td_simreads(C.byref(p), arr, len(barcodes), C.byref(out), C.byref(n)) != 0:
+        raise TdError("td_simreads failed")
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        lib.td_text_free(out)
