@@ -26,12 +26,35 @@
 #include "misc.h"
 
 #include "tagdust_hip.h"
+#include "tagdust_multi.h"
 
 int ref_run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, struct parameters* param,
                  struct fasta* reference_fasta, int numseq, int mode);
 
 static td_ctx* g_ctx = NULL;
+static td_multi* g_multi = NULL;   /* TAGDUST_HIP_DEVICES=0,1,...: the batches are shared out over these devices (tagdust_multi.h) */
 static uint64_t g_model_key = 0;
+
+/* one context on GPU 0, or -- with TAGDUST_HIP_DEVICES set -- one per listed device behind a td_multi (context 0 of it
+ * then also serves the calls that run on one device only: architecture comparison, windowed scores) */
+static int ensure_context(void)
+{
+	if (g_ctx) return TD_OK;
+	const char* e = getenv("TAGDUST_HIP_DEVICES");
+	if (e && *e) {
+		int32_t dev[64];
+		int n = 0;
+		while (*e && n < 64) {
+			dev[n++] = (int32_t)strtol(e, (char**)&e, 10);
+			while (*e == ',' || *e == ' ') e++;
+		}
+		if (td_multi_create(dev, n, &g_multi) != TD_OK) { fprintf(stderr, "tagdust_hip: %s\n", td_multi_last_error(NULL)); return TD_FAIL; }
+		g_ctx = td_multi_ctx(g_multi, 0);
+		return TD_OK;
+	}
+	if (td_ctx_create(0, &g_ctx) != TD_OK) { fprintf(stderr, "tagdust_hip: %s\n", td_last_error(NULL)); return TD_FAIL; }
+	return TD_OK;
+}
 
 /* FNV-1a over everything that defines the model, so a rebuilt model_bag (calibration, "long sequence" realloc)
  * is re-uploaded only when its tables changed */
@@ -115,8 +138,9 @@ static int upload_model(struct model_bag* mb, struct parameters* param, int with
 	key = fnv(key, d->sM, 4 * C); key = fnv(key, d->sI, 4 * C); key = fnv(key, d->label, 4 * H); key = fnv(key, d->A, 4 * H * H);
 	int rc = TD_OK;
 	if (key != g_model_key) {
-		rc = td_model_upload(g_ctx, d);
+		rc = g_multi ? td_multi_model_upload(g_multi, d) : td_model_upload(g_ctx, d);
 		if (rc == TD_OK) g_model_key = key;
+		else if (g_multi) fprintf(stderr, "tagdust_hip: %s\n", td_multi_last_error(g_multi));
 	}
 	flat_free(&fm);
 	return rc;
@@ -184,20 +208,20 @@ int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, s
 	}
 	if (numseq <= 0) return kslOK;
 
-	if (!g_ctx && td_ctx_create(0, &g_ctx) != TD_OK) {
-		fprintf(stderr, "tagdust_hip: %s\n", td_last_error(NULL));
-		return kslFAIL;
-	}
+	if (ensure_context() != TD_OK) return kslFAIL;
 	if (mode == MODE_ARCH_COMP) return arch_comparison(ab, ri, param, numseq);
 	if (td_set_option(g_ctx, "specialize", 1) != TD_OK) goto ERROR;
 	if (upload_model(mb, param, 1) != TD_OK) goto ERROR;
-	if (td_set_params(g_ctx, param->confidence_threshold, param->minlen, param->dust) != TD_OK) goto ERROR;
+	if ((g_multi ? td_multi_set_params(g_multi, param->confidence_threshold, param->minlen, param->dust)
+	             : td_set_params(g_ctx, param->confidence_threshold, param->minlen, param->dust)) != TD_OK) goto ERROR;
 	if (td_set_window(g_ctx, windowed ? param->matchstart : -1, windowed ? param->matchend : -1) != TD_OK) goto ERROR;
 	/* -ref: match_to_reference (barcode_hmm.c:2349-2351) moves to the device; it only runs in label mode */
 	if (mode == MODE_GET_LABEL && reference_fasta && param->reference_fasta) {
-		if (td_set_artifacts(g_ctx, reference_fasta->string, reference_fasta->s_index, reference_fasta->numseq,
-		                     param->filter_error, param->num_threads) != TD_OK) goto ERROR;
-	} else if (td_set_artifacts(g_ctx, NULL, NULL, 0, 0, 1) != TD_OK) goto ERROR;
+		if ((g_multi ? td_multi_set_artifacts(g_multi, reference_fasta->string, reference_fasta->s_index, reference_fasta->numseq,
+		                                      param->filter_error, param->num_threads)
+		             : td_set_artifacts(g_ctx, reference_fasta->string, reference_fasta->s_index, reference_fasta->numseq,
+		                                param->filter_error, param->num_threads)) != TD_OK) goto ERROR;
+	} else if ((g_multi ? td_multi_set_artifacts(g_multi, NULL, NULL, 0, 0, 1) : td_set_artifacts(g_ctx, NULL, NULL, 0, 0, 1)) != TD_OK) goto ERROR;
 
 	int64_t* offs = malloc(sizeof(int64_t) * ((size_t)numseq + 1));
 	offs[0] = 0;
@@ -208,9 +232,17 @@ int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, s
 	td_read_result* res = malloc(sizeof(td_read_result) * (size_t)numseq);
 	int8_t* labels = malloc((size_t)offs[numseq] + (size_t)numseq);
 	uint8_t* seq_out = malloc((size_t)offs[numseq] + 1);
-	if (td_batch_upload(g_ctx, codes, offs, numseq) != TD_OK ||
-	    td_run(g_ctx, mode == MODE_GET_LABEL ? TD_MODE_GET_LABEL : TD_MODE_GET_PROB) != TD_OK ||
-	    td_batch_download(g_ctx, res, mode == MODE_GET_LABEL ? labels : NULL, mode == MODE_GET_LABEL ? seq_out : NULL) != TD_OK) {
+	const int tdmode = mode == MODE_GET_LABEL ? TD_MODE_GET_LABEL : TD_MODE_GET_PROB;
+	int8_t* want_labels = mode == MODE_GET_LABEL ? labels : NULL;
+	uint8_t* want_seq = mode == MODE_GET_LABEL ? seq_out : NULL;
+	int failed;
+	if (g_multi && !windowed)   /* the batch split over the devices like run_pHMM splits it over threads, results in input order */
+		failed = td_multi_decode(g_multi, codes, 0, offs, numseq, tdmode, res, want_labels, want_seq) != TD_OK;
+	else
+		failed = td_batch_upload(g_ctx, codes, offs, numseq) != TD_OK || td_run(g_ctx, tdmode) != TD_OK ||
+		         td_batch_download(g_ctx, res, want_labels, want_seq) != TD_OK;
+	if (failed) {
+		if (g_multi && !windowed) fprintf(stderr, "tagdust_hip: %s\n", td_multi_last_error(g_multi));
 		status = kslFAIL;
 	} else {
 		for (i = 0; i < numseq; i++) {

@@ -34,8 +34,10 @@ def _write_fastq(g, path):
             fh.write(b"@" + names[i] + b"\n" + s + b"\n+\n" + q + b"\n")
 
 
-def _run(binary, args, cwd):
-    p = subprocess.run([os.path.join(RBIN, binary)] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+def _run(binary, args, cwd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([os.path.join(RBIN, binary)] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=e)
     assert p.returncode == 0, p.stdout.decode(errors="replace")[-2000:]
     return p.stdout.decode(errors="replace")
 
@@ -163,6 +165,28 @@ def test_reference_cli_with_artifact_filter(tmp_path, threads):
         lines = open(os.path.join(str(tmp_path), prefix + "_logfile.txt")).read().splitlines()
         return sorted(l.split("\t", 1)[1] for l in lines if "artifact_" in l)   # drop the time stamp
     assert hits("cpu") == hits("gpu") and hits("cpu")
+
+
+@pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("name,extra", [("artifacts_b_r", ["-t", "3"]), ("c3_b6_s_r_p", []), ("c2_indel_varlen", ["-t", "5"])])
+def test_reference_cli_over_several_contexts(tmp_path, name, extra):
+    """TAGDUST_HIP_DEVICES: the shim hands every batch to td_multi_decode, which splits it like run_pHMM splits it over
+    threads and merges in input order.  With one physical GPU the list names device 0 three times (three contexts, host sum
+    of the counters); the files must still equal the CPU reference's, artifact thread ranges included."""
+    g = load_golden(name)
+    fq = str(tmp_path / "in.fq")
+    _write_fastq(g, fq)
+    args = str(g["cmdline"]).split() + extra
+    if "-ref" in args:
+        fa = str(tmp_path / "art.fa")
+        open(fa, "wb").write(bytes(g["art_fasta_text"]))
+        args[args.index("-ref") + 1] = fa
+    _run("tagdust_rtest", args + [fq, "-o", "cpu"], str(tmp_path))
+    log = _run("tagdust_hip_rtest", args + [fq, "-o", "gpu"], str(tmp_path), env={"TAGDUST_HIP_DEVICES": "0,0,0"})
+    cpu, gpu = _outputs(str(tmp_path), "cpu"), _outputs(str(tmp_path), "gpu")
+    assert cpu and set(cpu) == set(gpu), (sorted(cpu), sorted(gpu), log[-1500:])
+    for k in cpu:
+        assert cpu[k] == gpu[k], "output file *%s differs" % k
 
 
 @pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built")
