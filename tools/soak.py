@@ -43,9 +43,21 @@ def worker(tag, iters, seed, errors):
             seqs = [g["seq"][offs_g[i]:offs_g[i + 1]] for i in pick] * reps
             offs = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int64)
             seq = np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)
-            c.upload_batch(seq, offs)
-            c.run()
-            res, labels, seq_after = c.download()
+            if it % 2 == 0:                         # the synchronous calls ...
+                c.upload_batch(seq, offs)
+                c.run()
+                res, labels, seq_after = c.download()
+            else:                                   # ... and the pipelined ones, two batches in flight
+                from tagdust_amd import RESULT_DTYPE
+                outs = [(np.zeros(len(offs) - 1, RESULT_DTYPE), np.zeros(int(offs[-1]) + len(offs) - 1, np.int8), np.zeros(int(offs[-1]), np.uint8))
+                        for _ in range(2)]
+                tk = [c.submit(seq, offs, res=o[0], labels=o[1], seq_out=o[2]) for o in outs]
+                for t_ in tk:
+                    c.wait(t_)
+                if outs[0][0].tobytes() != outs[1][0].tobytes() or not np.array_equal(outs[0][2], outs[1][2]):
+                    errors.append("%s: iteration %d: two submissions of one batch differ" % (tag, it))
+                    return
+                res, labels, seq_after = outs[1]
             for r in range(0, reps, max(1, reps // 2)):
                 sl = slice(r * n, (r + 1) * n)
                 if not (np.array_equal(res["read_type"][sl], g["read_type"][pick]) and np.array_equal(res["barcode"][sl], g["barcode"][pick])
