@@ -132,6 +132,7 @@ struct td_ctx {
 	// batches: slot 0 is the resident batch of the synchronous calls; td_submit rotates over pipeline_depth slots
 	TdSlot slots[TD_MAX_PIPELINE];
 	int pipeline_depth = 3, next_slot = 0, last_slot = 0;
+	int poison = 0;   // option "poison_workspace": fill the workspace with 0xFF bytes before every decode launch (tests)
 	int64_t ticket_counter = 0;
 	hipStream_t s_up = nullptr, s_down = nullptr;   // copy streams of the pipelined calls
 	uint8_t* d_ws = nullptr;      size_t cap_ws = 0;  // one workspace for all slots (decode kernels run one after the other)
@@ -499,6 +500,7 @@ extern "C" int td_set_option(td_ctx* c, const char* name, int32_t value)
 		c->specialize = value != 0; // takes effect at the next td_model_upload
 		return TD_OK;
 	}
+	if (!strcmp(name, "poison_workspace")) { c->poison = value != 0; return TD_OK; }
 	if (!strcmp(name, "pipeline_depth")) {
 		if (value < 1 || value > TD_MAX_PIPELINE) return fail(c, "td_set_option: pipeline_depth must be 1..%d", TD_MAX_PIPELINE);
 		if (tickets_outstanding(c)) return fail(c, "td_set_option: pipeline_depth cannot change while tickets are outstanding");
@@ -815,6 +817,9 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 		ka.art_text = c->d_art_text; ka.art_index = c->d_art_index; ka.art_left = s.d_art_left;
 		ka.art_n = c->art_n; ka.art_fe = c->art_fe;
 	}
+	// tests: every byte of the workspace the kernel reads must have been written by this launch -- garbage (NaN floats,
+	// all-ones masks) in place of whatever an earlier batch or model left there makes a read-before-write show
+	if (c->poison) HIPCHK(c, hipMemsetAsync(c->d_ws, 0xFF, (size_t)s.n_wave_slots * (size_t)s.ws_slot_bytes, c->stream));
 	HIPCHK(c, hipEventRecord(s.ev_k0, c->stream));
 	if (c->spec_ready) {
 		TdSpecArgs sa{};

@@ -116,6 +116,8 @@ struct TdSpecLayout {
 	int64_t bm;      // f32   [lmax+2][64]  running maximum of the first segment's label sums (kFirstN > 0)
 	int64_t ba;      // u8    [lmax+2][64]  the label holding it
 	int64_t acc;     // f32   [2][H][64]  label-DP rows (previous / current position) when too many labels for registers
+	int64_t pmask;   // u32   [H][ceil(lmax/32)]  per wave, not per lane: bit i-1 of label h = the posterior row (h, i) was stored
+	                 //       (some read of the tile has a non-zero posterior there); rows never stored are read as 0
 };
 
 struct TdSpecArgs {

@@ -25,6 +25,7 @@ def ctx(request):
     from tagdust_amd import TagdustHip
     c = TagdustHip(0)
     c.set_option("specialize", request.param)
+    c.set_option("poison_workspace", 1)      # stale workspace contents must never reach a result
     yield c
     c.close()
 

@@ -18,6 +18,7 @@ def _ctx(g, specialize=1, depth=2):
     c = TagdustHip(0)
     c.set_option("specialize", specialize)
     c.set_option("pipeline_depth", depth)
+    c.set_option("poison_workspace", 1)
     c.upload_model(g)
     c.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
     return c
