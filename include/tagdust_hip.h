@@ -133,10 +133,12 @@ int td_set_artifacts(td_ctx* ctx, const uint8_t* string, const int32_t* s_index,
                      int32_t filter_error, int32_t n_threads);
 /* -start / -end (param->matchstart, param->matchend; -1, -1 = none): do_probability_estimation / do_label_thread then
  * decode seq + matchstart for matchend - matchstart bases (src/barcode_hmm.c:2195-2210, :2290-2313).  With a window set,
- * batches uploaded afterwards are cut to it on the device and TD_MODE_GET_PROB / TD_MODE_ARCH_COMP score the window.
- * The reference reads past the end of a read shorter than matchend (undefined); here such a read is scored on what it
- * has inside the window.  TD_MODE_GET_LABEL is refused while a window is set: what extract_reads / make_extracted_read
- * do with window labels on whole-read positions stays with the reference's own code. */
+ * td_run works on it in every mode and reproduces what the reference does with the window's labels afterwards:
+ * extract_reads walks them (:3189-3193, fingerprint bases from seq[j + matchstart]); make_extracted_read (:3325-3356)
+ * puts label j+1 on position j of the WHOLE read and meets ri->labels' initial zeros beyond the window (io.c:1755-1764),
+ * i.e. HMM 0 of segment 0; the artifact filter and DUST see that rewritten whole read; labels beyond the window are 0.
+ * The reference reads past the end of a read shorter than matchend (undefined); here such a read is decoded on what it
+ * has inside the window. */
 int td_set_window(td_ctx* ctx, int32_t matchstart, int32_t matchend);
 /* The batches this context gets from now on are reads [first_read, first_read + n) of a batch of total_reads reads that is
  * shared out over several contexts (tagdust_multi.h): the artifact filter's thread ranges are then taken over the whole

@@ -196,11 +196,10 @@ int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, s
 	int i, k, status = kslOK;
 
 	const int windowed = param->matchstart != -1 || param->matchend != -1;
-	/* not on the GPU path: training modes; -start/-end windows except for the scores (MODE_GET_PROB) of reads that reach
-	   matchend -- the reference reads past the end of a shorter read there, and in label mode applies window labels to
-	   whole-read positions (barcode_hmm.c:3325-3356), which stays with its own code */
+	/* not on the GPU path: the dead training modes; -start/-end windows when a read does not reach matchend -- the
+	   reference reads past the end of such a read (undefined), so its own code keeps that case */
 	if ((mode != MODE_GET_LABEL && mode != MODE_GET_PROB && mode != MODE_ARCH_COMP) || (mode == MODE_ARCH_COMP && !ab) ||
-	    (windowed && mode != MODE_GET_PROB))
+	    (windowed && mode == MODE_ARCH_COMP))
 		return ref_run_pHMM(ab, mb, ri, param, reference_fasta, numseq, mode);
 	if (windowed) {
 		if (param->matchstart < 0 || param->matchend <= param->matchstart) return ref_run_pHMM(ab, mb, ri, param, reference_fasta, numseq, mode);
@@ -236,7 +235,7 @@ int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, s
 	int8_t* want_labels = mode == MODE_GET_LABEL ? labels : NULL;
 	uint8_t* want_seq = mode == MODE_GET_LABEL ? seq_out : NULL;
 	int failed;
-	if (g_multi && !windowed)   /* the batch split over the devices like run_pHMM splits it over threads, results in input order */
+	if (g_multi && !windowed)   /* (a window is applied by one context; td_multi has no window call) -- the batch split over the devices like run_pHMM splits it over threads, results in input order */
 		failed = td_multi_decode(g_multi, codes, 0, offs, numseq, tdmode, res, want_labels, want_seq) != TD_OK;
 	else
 		failed = td_batch_upload(g_ctx, codes, offs, numseq) != TD_OK || td_run(g_ctx, tdmode) != TD_OK ||

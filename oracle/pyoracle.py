@@ -30,7 +30,7 @@ class _Model(C.Structure):
 
 
 class _Params(C.Structure):
-    _fields_ = [("threshold", C.c_float), ("minlen", C.c_int32), ("dust", C.c_int32)]
+    _fields_ = [("threshold", C.c_float), ("minlen", C.c_int32), ("dust", C.c_int32), ("matchstart", C.c_int32), ("matchend", C.c_int32)]
 
 
 class _Artifacts(C.Structure):
@@ -113,10 +113,11 @@ class OracleModel:
         self.c = m
 
 
-def label_batch(model, seqs, offs, threshold, minlen=16, dust=100, n_threads=1, artifacts=None):
+def label_batch(model, seqs, offs, threshold, minlen=16, dust=100, n_threads=1, artifacts=None, window=None):
     """Run the oracle over a batch.  seqs: uint8 codes (0..4) concatenated; offs: int64 [n+1].
     artifacts: None or (string uint8, s_index int32 [n_seq+1], filter_error) -- struct fasta as read_fasta() leaves
     it; matching depends on n_threads (match_to_reference pairs reads in fours per thread range).
+    window: None or (matchstart, matchend) of -start / -end.
     Returns (results structured array, labels int8 laid out at offs[i]+i with len+1 entries,
     seq_after uint8)."""
     L = lib()
@@ -125,7 +126,7 @@ def label_batch(model, seqs, offs, threshold, minlen=16, dust=100, n_threads=1, 
     seq_after = np.array(seqs, dtype=np.uint8, copy=True)
     labels = np.zeros(int(offs[-1]) + n, dtype=np.int8)
     res = np.zeros(n, dtype=RESULT_DTYPE)
-    p = _Params(float(threshold), int(minlen), int(dust))
+    p = _Params(float(threshold), int(minlen), int(dust), -1 if window is None else int(window[0]), -1 if window is None else int(window[1]))
     art = None
     if artifacts is not None:
         a_str = np.ascontiguousarray(artifacts[0], dtype=np.uint8)

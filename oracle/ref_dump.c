@@ -167,8 +167,16 @@ int main(int argc, char* argv[])
 		int len = ri[i]->len;
 		seq_before[i] = malloc(len + 1);
 		memcpy(seq_before[i], ri[i]->seq, len + 1);
-		mb = backward(mb, ri[i]->seq, len);
-		mb = forward_max_posterior_decoding(mb, ri[i], ri[i]->seq, len);
+		if(param->matchstart != -1 || param->matchend != -1){
+			/* -start / -end: do_label_thread decodes seq + matchstart for matchend - matchstart bases (barcode_hmm.c:2290-2296);
+			   only reads that reach matchend are defined input (the reference reads past a shorter read's terminator) */
+			if(len < param->matchend){ fprintf(stderr, "ref_dump: read %d (%d nt) does not reach -end %d\n", i, len, param->matchend); return 1; }
+			mb = backward(mb, ri[i]->seq + param->matchstart, param->matchend - param->matchstart);
+			mb = forward_max_posterior_decoding(mb, ri[i], ri[i]->seq + param->matchstart, param->matchend - param->matchstart);
+		}else{
+			mb = backward(mb, ri[i]->seq, len);
+			mb = forward_max_posterior_decoding(mb, ri[i], ri[i]->seq, len);
+		}
 		bs[i] = mb->b_score; fs[i] = mb->f_score; rsx[i] = mb->r_score; bp[i] = ri[i]->bar_prob;
 		lab[i] = malloc(len + 1);
 		memcpy(lab[i], ri[i]->labels, len + 1);

@@ -421,6 +421,12 @@ static void make_extracted(const tdo_model* m, uint8_t* seq, uint8_t* qual, int 
 void tdo_extract(const tdo_model* m, const tdo_params* p, uint8_t* seq, uint8_t* qual, int len,
                  const int8_t* labels, float Q, int32_t* read_type, int32_t* barcode, int32_t* fingerprint)
 {
+	tdo_extract_window(m, p, seq, qual, len, 0, len, labels, Q, read_type, barcode, fingerprint);
+}
+
+void tdo_extract_window(const tdo_model* m, const tdo_params* p, uint8_t* seq, uint8_t* qual, int len, int woff, int wlen,
+                        const int8_t* labels, float Q, int32_t* read_type, int32_t* barcode, int32_t* fingerprint)
+{
 	int j, c1, c2, c3;
 	uint32_t key = 0;
 	int bar = -1, mem = -1, fingerlen = 0, required = 0;
@@ -433,13 +439,13 @@ void tdo_extract(const tdo_model* m, const tdo_params* p, uint8_t* seq, uint8_t*
 		*read_type = TDO_FAIL_ARCHITECTURE_MISMATCH;
 		return;
 	}
-	for (j = 0; j < len; j++) { /* :3205-3242 */
+	for (j = 0; j < wlen; j++) { /* :3205-3242; with a window len = matchend - matchstart, offset = matchstart (:3189-3193) */
 		c1 = m->label[(int)labels[j + 1]];
 		c2 = c1 & 0xFFFF;
 		c3 = (c1 >> 16) & 0x7FFF;
 		if (m->type[c2] == 'F') {
 			fingerlen++;
-			key = (key << 2) | (uint32_t)(seq[j] & 0x3);
+			key = (key << 2) | (uint32_t)(seq[j + woff] & 0x3);
 		}
 		if (m->type[c2] == 'B') {
 			has_bar = 1;
@@ -643,10 +649,19 @@ void tdo_label_read(const tdo_model* m, const tdo_params* p, tdo_workspace* ws,
 	res->read_type = 0;  /* clear_read_info, io.c:2084-2094 */
 	res->barcode = -1;
 	res->fingerprint = -1;
-	res->b_score = tdo_backward(m, ws, seq, len);
-	tdo_forward_decode(m, ws, seq, len, res->b_score, &res->f_score, &res->r_score, &res->bar_prob, labels);
+	int woff = 0, wlen = len;
+	if (p->matchend > 0 && p->matchstart >= 0 && p->matchend > p->matchstart) {
+		/* do_label_thread :2290-2296.  The reference reads past the terminator of a read that ends before matchend
+		 * (undefined); here -- and on the device -- such a read is decoded on what it has inside the window. */
+		const int e = len < p->matchend ? len : p->matchend;
+		woff = p->matchstart;
+		wlen = e > woff ? e - woff : 0;
+		memset(labels, 0, (size_t)len + 1);     /* ri->labels as read_fasta_fastq() leaves it, io.c:1755-1764 */
+	}
+	res->b_score = tdo_backward(m, ws, seq + woff, wlen);
+	tdo_forward_decode(m, ws, seq + woff, wlen, res->b_score, &res->f_score, &res->r_score, &res->bar_prob, labels);
 	res->Q = tdo_qvalue(res->f_score, res->r_score, res->bar_prob);
-	tdo_extract(m, p, seq, qual, len, labels, res->Q, &res->read_type, &res->barcode, &res->fingerprint);
+	tdo_extract_window(m, p, seq, qual, len, woff, wlen, labels, res->Q, &res->read_type, &res->barcode, &res->fingerprint);
 	if (p->dust && tdo_dust(seq, len, p->dust)) res->read_type = TDO_FAIL_LOW_COMPLEXITY;
 }
 

@@ -65,6 +65,8 @@ typedef struct tdo_params {
 	float   threshold;         /* param->confidence_threshold in effect */
 	int32_t minlen;            /* param->minlen */
 	int32_t dust;              /* param->dust (0 = off) */
+	int32_t matchstart;        /* param->matchstart / matchend (-start / -end): the read is decoded on seq + matchstart for */
+	int32_t matchend;          /* matchend - matchstart bases (barcode_hmm.c:2290-2296); both <= 0 (or -1): whole reads    */
 } tdo_params;
 
 /* per-read results */
@@ -96,6 +98,11 @@ float tdo_qvalue(float f_score, float r_score, float bar_prob);
  * on success exactly like the reference (non-read positions -> 65). qual may be NULL. */
 void  tdo_extract(const tdo_model* m, const tdo_params* p, uint8_t* seq, uint8_t* qual, int len,
                   const int8_t* labels, float Q, int32_t* read_type, int32_t* barcode, int32_t* fingerprint);
+/* the same with a -start/-end window (extract_reads :3189-3193): labels[1..wlen] describe seq[woff .. woff+wlen); the
+ * rewrite (make_extracted_read :3325-3356) still walks the whole read with labels[j+1] on position j, and beyond the
+ * window meets the zeros read_fasta_fastq() put into ri->labels (io.c:1755-1764) */
+void  tdo_extract_window(const tdo_model* m, const tdo_params* p, uint8_t* seq, uint8_t* qual, int len, int woff, int wlen,
+                         const int8_t* labels, float Q, int32_t* read_type, int32_t* barcode, int32_t* fingerprint);
 /* dust_sequences, barcode_hmm.c:2407-2467 (one read); returns 1 if low complexity */
 int   tdo_dust(const uint8_t* seq, int len, int dust_cut);
 

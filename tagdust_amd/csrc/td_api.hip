@@ -49,7 +49,6 @@ struct TdSlot {
 	int is_ascii = 0, mode = 0;
 	bool sorted = false;      // device order differs from the caller's (reads of several lengths)
 	bool staged = false;      // inputs are packed on the device: td_run may launch
-	bool windowed = false;    // packed through a -start / -end window
 	bool ran = false, finished = false;
 	float last_ms = -1.0f;
 	int64_t ticket = 0;       // td_submit: 0 = free
@@ -116,6 +115,7 @@ struct td_ctx {
 	std::vector<int8_t> m_seg_type;
 	std::vector<int32_t> m_finger_len;
 	bool spec_oob = false;      // the loaded kernel uses the clamp-free logsum
+	bool spec_window = false;   // the loaded kernel has the -start/-end window arithmetic compiled in
 	bool spec_oob_unsafe = false; // the clamp-free form failed its self-check once: never again in this context
 	float m_maxabs = 0.0f;      // largest |finite parameter|
 	int spec_block = 256, spec_waves_per_cu = 8;
@@ -279,13 +279,14 @@ extern "C" void td_ctx_destroy(td_ctx* c)
 // model
 // ---------------------------------------------------------------------------------------------------------
 // Compile (or fetch from the cache) and load the model-specialised kernel.  lsum_oob selects the clamp-free logsum.
-static int load_spec_kernel(td_ctx* c, int lsum_oob)
+static int load_spec_kernel(td_ctx* c, int lsum_oob, int window = -1)
 {
+	if (window < 0) window = c->match_len > 0;   // a context with a -start/-end window gets the kernel that can apply it
 	if (c->spec_mod) { HIPCHK(c, hipModuleUnload(c->spec_mod)); c->spec_mod = nullptr; }
 	c->spec_fn = nullptr; c->spec_ready = false;
 	std::vector<char> code;
 	std::string log;
-	if (td_spec_compile(&c->m_desc, code, log, lsum_oob) != TD_OK) return fail(c, "td_model_upload: specialised kernel did not compile: %.400s", log.c_str());
+	if (td_spec_compile(&c->m_desc, code, log, lsum_oob, window) != TD_OK) return fail(c, "td_model_upload: specialised kernel did not compile: %.400s", log.c_str());
 	HIPCHK(c, hipModuleLoadData(&c->spec_mod, code.data()));
 	HIPCHK(c, hipModuleGetFunction(&c->spec_fn, c->spec_mod, "td_spec_kernel"));
 	// lsum() as compiled against the reference's formula on the operand pairs that matter (either or both operands -inf,
@@ -321,10 +322,11 @@ static int load_spec_kernel(td_ctx* c, int lsum_oob)
 			if (!lsum_oob) return fail(c, "td_model_upload: the compiled logsum differs from the reference formula on %d of %d operand pairs", bad, n_pairs);
 			fprintf(stderr, "tagdust_hip: clamp-free logsum failed its self-check on this device / toolchain (%d of %d pairs); using the clamped form\n", bad, n_pairs);
 			c->spec_oob_unsafe = true;
-			return load_spec_kernel(c, 0);
+			return load_spec_kernel(c, 0, window);
 		}
 	}
 	c->spec_ready = true;
+	c->spec_window = window != 0;
 	c->spec_oob = lsum_oob != 0;
 	return TD_OK;
 }
@@ -721,13 +723,8 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 		const int64_t l = offs[i + 1] - offs[i];
 		s.h_offs[i + 1] = offs[i + 1] - base;
 		if (l < 0 || l > 100000) { bad = i; break; }
-		int lw = (int)l;
-		if (c->match_len > 0) {   // the decode kernels see the window only
-			const int e = lw < c->match_start + c->match_len ? lw : c->match_start + c->match_len;
-			lw = e > c->match_start ? e - c->match_start : 0;
-		}
-		if (lw > lmax) lmax = lw;
-		if (lw < lmin) lmin = lw;
+		if (l > lmax) lmax = (int)l;
+		if (l < lmin) lmin = (int)l;
 	}
 	if (bad >= 0) return fail(c, "td_batch_upload: read %lld has length %lld", (long long)bad, (long long)(offs[bad + 1] - offs[bad]));
 	const int64_t n_bases = n > 0 ? offs[n] - base : 0;
@@ -767,14 +764,12 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 		HIPCHK(c, hipStreamWaitEvent(c->stream, s.ev_up, 0));
 	}
 	if (sorted)
-		HIPCHK(c, td_stage_sort(s.d_offs, n, lmax, c->match_start, c->match_len, s.d_read_at, s.d_keys, s.d_keys + n, s.d_vals, s.d_sort_tmp, sort_tmp, c->stream));
+		HIPCHK(c, td_stage_sort(s.d_offs, n, lmax, s.d_read_at, s.d_keys, s.d_keys + n, s.d_vals, s.d_sort_tmp, sort_tmp, c->stream));
 	TdStageBatch& b = s.sb;
 	b = TdStageBatch{};
 	b.raw = s.d_raw; b.offs = s.d_offs; b.n_reads = n; b.is_ascii = is_ascii;
 	b.n_tiles = (int32_t)n_tiles; b.lmax = lmax; b.nw2 = nw2; b.nw1 = nw1;
 	b.read_at = sorted ? s.d_read_at : nullptr;
-	b.win_start = c->match_start; b.win_len = c->match_len;
-	s.windowed = c->match_len > 0;
 	b.packed = s.d_packed; b.lens = s.d_lens; b.art_left = s.d_art_left;
 	b.out_soa = s.d_out; b.soa_stride = ol.soa_stride;
 	b.keep = (const uint32_t*)(s.d_out + ol.keep); b.labels = (const int8_t*)(s.d_out + ol.labels);
@@ -791,11 +786,13 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 	if (!c->have_model) return fail(c, "td_run: no model uploaded");
 	if (mode != TD_MODE_GET_LABEL && mode != TD_MODE_GET_PROB && mode != TD_MODE_ARCH_COMP) return fail(c, "td_run: unsupported mode %d", mode);
 	if (!s.staged) return fail(c, "td_run: no batch resident (td_batch_upload failed or was not called)");
-	if (s.windowed && mode == TD_MODE_GET_LABEL)
-		return fail(c, "td_run: TD_MODE_GET_LABEL through a -start/-end window is not on the device path (only the scores are defined there)");
 	HIPCHK(c, hipSetDevice(c->device));
 	s.mode = mode; s.finished = false;
 	if (s.n_tiles == 0) { s.ran = true; s.last_ms = 0.0f; return TD_OK; }
+	if (c->spec_ready && c->match_len > 0 && !c->spec_window) {   // first batch through a window: the kernel variant that applies it
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		if (load_spec_kernel(c, c->spec_oob ? 1 : 0, 1) != TD_OK) return TD_FAIL;
+	}
 	const OutLayout ol = out_layout(s.n_tiles, s.lmax, s.nw1);
 	TdKernelArgs ka{};
 	ka.hdr = c->d_hdr; ka.cols = c->d_cols; ka.hinfo = c->d_hinfo;
@@ -803,6 +800,7 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 	ka.packed = s.d_packed; ka.lens = s.d_lens;
 	ka.n_tiles = s.n_tiles; ka.n_slots = s.n_wave_slots; ka.lmax = s.lmax; ka.nw2 = s.nw2; ka.nw1 = s.nw1;
 	ka.mode = mode; ka.threshold = c->threshold; ka.minlen = c->minlen; ka.dust = c->dust; ka.want_labels = 1;
+	ka.win_start = c->match_start; ka.win_len = c->match_len;
 	float* soa = (float*)s.d_out;
 	const int64_t st = ol.soa_stride / 4;
 	ka.out_f = soa; ka.out_b = soa + st; ka.out_r = soa + 2 * st; ka.out_bar = soa + 3 * st; ka.out_q = soa + 4 * st;
@@ -826,6 +824,7 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 		sa.logsum = ka.logsum; sa.packed = ka.packed; sa.lens = ka.lens;
 		sa.n_tiles = ka.n_tiles; sa.n_slots = ka.n_slots; sa.lmax = ka.lmax; sa.nw2 = ka.nw2; sa.nw1 = ka.nw1;
 		sa.mode = ka.mode; sa.threshold = ka.threshold; sa.minlen = ka.minlen; sa.dust = ka.dust;
+		sa.win_start = ka.win_start; sa.win_len = ka.win_len;
 		sa.out_f = ka.out_f; sa.out_b = ka.out_b; sa.out_r = ka.out_r; sa.out_bar = ka.out_bar; sa.out_q = ka.out_q;
 		sa.out_type = ka.out_type; sa.out_barcode = ka.out_barcode; sa.out_finger = ka.out_finger;
 		sa.out_keep = ka.out_keep; sa.out_labels = ka.out_labels; sa.counters = ka.counters;
@@ -867,7 +866,6 @@ static int slot_issue_copies(td_ctx* c, TdSlot& s, hipStream_t down)
 static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* labels, uint8_t* seq_out, bool deferred)
 {
 	if (!s.ran) return fail(c, "td_batch_download: td_run has not been called on this batch");
-	if (s.windowed && (labels || seq_out)) return fail(c, "td_batch_download: labels / sequences are not available through a -start/-end window");
 	s.u_res = res; s.u_labels = labels; s.u_seq = seq_out;
 	s.res_direct = s.lab_direct = s.seq_direct = false;
 	s.copies_deferred = deferred;

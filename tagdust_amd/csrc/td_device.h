@@ -78,6 +78,7 @@ struct TdKernelArgs {
 	float   threshold;
 	int32_t minlen, dust;
 	int32_t want_labels;
+	int32_t win_start, win_len;             // -start / -end window for the DP phases; win_len = 0: whole reads
 	// outputs
 	float*   __restrict__ out_f;           // [n_tiles*64] each
 	float*   __restrict__ out_b;
@@ -128,6 +129,7 @@ struct TdSpecArgs {
 	int32_t mode;
 	float   threshold;
 	int32_t minlen, dust;
+	int32_t win_start, win_len;             // -start / -end window for the DP phases; win_len = 0: whole reads
 	int32_t pad0;
 	float*   __restrict__ out_f;
 	float*   __restrict__ out_b;

@@ -13,8 +13,8 @@ int td_spec_block_threads(void);
 int td_spec_min_waves(void);
 int td_spec_first_labels(const td_model_desc* m);   /* labels whose posteriors the forward sweep sums up itself (0: none) */
 int td_spec_lsum_oob(void);      /* 1: clamp-free logsum (LDS out-of-range reads as 0), see td_spec_kernel.inc */
-std::string td_spec_model_section(const td_model_desc* m, int lsum_oob = -1);   /* lsum_oob < 0: td_spec_lsum_oob() */
-std::string td_spec_full_source(const td_model_desc* m, int lsum_oob = -1);
+std::string td_spec_model_section(const td_model_desc* m, int lsum_oob = -1, int window = 0);   /* lsum_oob < 0: td_spec_lsum_oob(); window: -start/-end support compiled in */
+std::string td_spec_full_source(const td_model_desc* m, int lsum_oob = -1, int window = 0);
 void td_spec_layout(TdSpecLayout& L, const td_model_desc* m, int lmax);
 std::string td_spec_cache_dir(void);   /* on-disk cache of compiled kernels ("" = off) */
-int td_spec_compile(const td_model_desc* m, std::vector<char>& code, std::string& log, int lsum_oob = -1);
+int td_spec_compile(const td_model_desc* m, std::vector<char>& code, std::string& log, int lsum_oob = -1, int window = 0);

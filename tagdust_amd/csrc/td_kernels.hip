@@ -463,7 +463,7 @@ __device__ __forceinline__ void decode_body(const TdKernelArgs& ka, const int bl
 	w.lane = lane;
 	w.lmax = lmax;
 
-	uint8_t* codes = w.slot + ka.lay.codes;
+	uint8_t* const codesF = w.slot + ka.lay.codes;   // base codes of the whole reads
 	float* SB = ws_f32(w, ka.lay.sb);
 	float* SF = ws_f32(w, ka.lay.sf);
 	float2* BW = (float2*)(w.slot + ka.lay.bw);
@@ -476,27 +476,41 @@ __device__ __forceinline__ void decode_body(const TdKernelArgs& ka, const int bl
 
 	for (int tile = slot; tile < ka.n_tiles; tile += ka.n_slots) {
 		const int64_t rid = (int64_t)tile * TD_WAVE + lane;
-		const int len = ka.lens[rid];
+		// -start / -end (td_set_window): `len`, `tmax`, `codes` describe the window the DP phases see (do_label_thread decodes
+		// seq + matchstart for matchend - matchstart bases, barcode_hmm.c:2290-2296); `lenF`, `tmaxF`, `codesF` the whole
+		// read, which the rewrite, the artifact filter and DUST walk (make_extracted_read :3336)
+		const int lenF = ka.lens[rid];
+		const int woff = ka.win_len > 0 ? ka.win_start : 0;
+		int len = lenF;
+		if (ka.win_len > 0) {
+			const int e = lenF < woff + ka.win_len ? lenF : woff + ka.win_len;
+			len = e > woff ? e - woff : 0;
+		}
 		w.len = len;
 		int tmax = len;
 #pragma unroll
 		for (int o = 32; o >= 1; o >>= 1) tmax = max(tmax, __shfl_xor(tmax, o));
 		tmax = __builtin_amdgcn_readfirstlane(tmax);
 		w.tmax = tmax;
+		int tmaxF = lenF;
+#pragma unroll
+		for (int o = 32; o >= 1; o >>= 1) tmaxF = max(tmaxF, __shfl_xor(tmaxF, o));
+		tmaxF = __builtin_amdgcn_readfirstlane(tmaxF);
+		uint8_t* const codes = codesF + woff * TD_WAVE;
 
 		// ---- phase 0: unpack 2-bit codes + N mask into x_0..x_{tmax+1} (x_0 and x_{>len} = 0) ----
 		{
 			const uint32_t* pk = ka.packed + (int64_t)tile * (ka.nw2 + ka.nw1) * TD_WAVE;
-			codes[lane] = 0;
+			codesF[lane] = 0;
 			uint32_t w2 = 0, w1 = 0;
-			for (int i = 1; i <= tmax + 1; i++) {
+			for (int i = 1; i <= tmaxF + 1; i++) {
 				const int k = i - 1;
 				if ((k & 15) == 0) w2 = (k >> 4) < ka.nw2 ? pk[(k >> 4) * TD_WAVE + lane] : 0u;
 				if ((k & 31) == 0) w1 = (k >> 5) < ka.nw1 ? pk[(ka.nw2 + (k >> 5)) * TD_WAVE + lane] : 0u;
 				uint32_t code = (w2 >> (2 * (k & 15))) & 3u;
 				if ((w1 >> (k & 31)) & 1u) code = 4u;
-				if (i > len) code = 0u;
-				codes[i * TD_WAVE + lane] = (uint8_t)code;
+				if (i > lenF) code = 0u;
+				codesF[i * TD_WAVE + lane] = (uint8_t)code;
 			}
 		}
 
@@ -663,6 +677,11 @@ __device__ __forceinline__ void decode_body(const TdKernelArgs& ka, const int bl
 				}
 			}
 
+			// with a window, ri->labels beyond it keeps the zeros read_fasta_fastq() put there (io.c:1755-1764)
+			if (ka.win_len > 0) {
+				for (int i = 1; i <= tmaxF; i++)
+					if (i > len && i <= lenF) labels[i * TD_WAVE + lane] = 0;
+			}
 			// ---- extract_reads, :3172-3313 ----
 			bool extracted = false;
 			for (int k = 0; k < nw1; k++) keep[k * TD_WAVE + lane] = 0xFFFFFFFFu;
@@ -673,7 +692,11 @@ __device__ __forceinline__ void decode_body(const TdKernelArgs& ka, const int bl
 				int bar = -1, mem = -1, fingerlen = 0, s_pos = 0, has_bar = 0;
 				bool too_short = false, in_read = false, stopped = false;
 				uint32_t kw = 0;
-				for (int jx = 0; jx < tmax; jx++) {
+				// make_extracted_read (:3336-3352) walks the whole read with labels[j+1] on position j: beyond a window those
+				// labels are 0, i.e. HMM 0 of segment 0 -- kept only if that segment is a read segment
+				const bool tail_kept = (ka.hinfo[0] & 0xFF) == 'R';
+				const int xmax = ka.win_len > 0 ? tmaxF : tmax;
+				for (int jx = 0; jx < xmax; jx++) {
 					if (jx < len) {
 						const uint32_t hi = ka.hinfo[(int)labels[(jx + 1) * TD_WAVE + lane]];
 						const int ty = hi & 0xFF;
@@ -697,8 +720,10 @@ __device__ __forceinline__ void decode_body(const TdKernelArgs& ka, const int bl
 							}
 						}
 						if (ty == 'R') kw |= 1u << (jx & 31);
+					} else if (jx < lenF && tail_kept) {
+						kw |= 1u << (jx & 31);
 					}
-					if ((jx & 31) == 31 || jx == tmax - 1) { keep[(jx >> 5) * TD_WAVE + lane] = kw; kw = 0; }
+					if ((jx & 31) == 31 || jx == xmax - 1) { keep[(jx >> 5) * TD_WAVE + lane] = kw; kw = 0; }
 				}
 				if (in_read && s_pos < ka.minlen) too_short = true;
 				const int req = hd.required_finger_len;
@@ -726,22 +751,22 @@ __device__ __forceinline__ void decode_body(const TdKernelArgs& ka, const int bl
 
 			// ---- match_to_reference, :2478-2583 (td_artifact.inc) ----
 			if (ka.art_n > 0) {
-				const uint8_t* cd = codes;
+				const uint8_t* cd = codesF;
 				auto sq = [&](int kk) -> int {
 					return ((keep[(kk >> 5) * TD_WAVE + lane] >> (kk & 31)) & 1u) ? (int)cd[(kk + 1) * TD_WAVE + lane] : 65;
 				};
-				const int id = td_art_match(sq, len, tmax, ka.art_left[rid] != 0, ka.art_text, ka.art_index, ka.art_n, ka.art_fe);
+				const int id = td_art_match(sq, lenF, tmaxF, ka.art_left[rid] != 0, ka.art_text, ka.art_index, ka.art_n, ka.art_fe);
 				if (id > 0 && read_type == OUT_SUCCESS) read_type = (id << 8) | OUT_MATCHES_ARTIFACTS;
 			}
 
 			// ---- dust_sequences, :2407-2467, on the rewritten sequence ----
-			if (ka.dust && len >= 1) {
-#define SQ(kk) (((kk) < len) ? ((((keep[((kk) >> 5) * TD_WAVE + lane] >> ((kk) & 31)) & 1u)) ? (int)codes[((kk) + 1) * TD_WAVE + lane] : 65) : 0)
+			if (ka.dust && lenF >= 1) {
+#define SQ(kk) (((kk) < lenF) ? ((((keep[((kk) >> 5) * TD_WAVE + lane] >> ((kk) & 31)) & 1u)) ? (int)codesF[((kk) + 1) * TD_WAVE + lane] : 65) : 0)
 				for (int k = 0; k < 64; k++) DUST[k * TD_WAVE + lane] = 0;
 				int c0 = 0;
 				while (SQ(c0) == 65) c0++;
 				int key = ((SQ(c0) & 3) << 2) | (SQ(c0 + 1) & 3);
-				const int n = len > 64 ? 64 : len;
+				const int n = lenF > 64 ? 64 : lenF;
 				int cc = c0 + 2;
 				for (int jx = c0 + 2; jx < n; jx++) {
 					const int s = SQ(jx);
@@ -762,7 +787,7 @@ __device__ __forceinline__ void decode_body(const TdKernelArgs& ka, const int bl
 		}
 
 		// ---- per-read outputs + counters ----
-		if (len >= 1 || ka.lens[rid] == 0) {
+		if (lenF >= 1 || ka.lens[rid] == 0) {
 			ka.out_f[rid] = f_score;
 			ka.out_b[rid] = b_score;
 			ka.out_r[rid] = r_score;
@@ -772,7 +797,7 @@ __device__ __forceinline__ void decode_body(const TdKernelArgs& ka, const int bl
 			ka.out_barcode[rid] = barcode;
 			ka.out_finger[rid] = fingerprint;
 		}
-		if (ka.mode == MODE_GET_LABEL && len >= 1) {
+		if (ka.mode == MODE_GET_LABEL && lenF >= 1) {
 			atomicAdd(&ka.counters[read_type & (N_OUTCOME_SLOTS - 1)], 1ull);
 			if (read_type == OUT_SUCCESS && barcode >= 0) atomicAdd(&ka.counters[N_OUTCOME_SLOTS + (barcode & 0xFF)], 1ull);
 		}

@@ -17,9 +17,6 @@ struct TdStageBatch {
 	int32_t is_ascii;
 	int32_t n_tiles, lmax, nw2, nw1;
 	const int32_t* read_at;   // [n] or nullptr
-	// -start / -end window (td_set_window): the decode kernels see bases [win_start, win_start + win_len) of every read
-	// (clipped to the read); win_len = 0: whole reads
-	int32_t win_start, win_len;
 	// -ref artifact filter: reads of each thread range are taken in fours, the remainder goes to another routine
 	// (match_to_reference, src/barcode_hmm.c:2495-2575; ranges as in run_pHMM :1911-1922).  art_threads = 0: off
 	int32_t art_threads;
@@ -41,8 +38,8 @@ struct TdStageBatch {
 // bytes of scratch td_stage_sort needs for n reads
 size_t td_stage_sort_temp_bytes(int64_t n_reads, int lmax);
 // read_at <- stable sort of the read indices by length; keys / keys_alt / vals_alt: [n] scratch, temp: td_stage_sort_temp_bytes
-hipError_t td_stage_sort(const int64_t* offs, int64_t n_reads, int lmax, int win_start, int win_len, int32_t* read_at, uint32_t* keys,
-                         uint32_t* keys_alt, int32_t* vals_alt, void* temp, size_t temp_bytes, hipStream_t stream);
+hipError_t td_stage_sort(const int64_t* offs, int64_t n_reads, int lmax, int32_t* read_at, uint32_t* keys, uint32_t* keys_alt,
+                         int32_t* vals_alt, void* temp, size_t temp_bytes, hipStream_t stream);
 // raw bases -> 2-bit words + N mask, lane-interleaved per tile; lens
 hipError_t td_stage_pack(const TdStageBatch& b, hipStream_t stream);
 // art_left[k] = read k is a left-over read of its thread range (art_threads ranges over the caller's order)

@@ -18,17 +18,12 @@
 #define STAGE_BLOCK 256
 
 // read lengths as sort keys + identity values
-__global__ __launch_bounds__(STAGE_BLOCK) void td_len_iota_kernel(const int64_t* __restrict__ offs, int64_t n, int win_start, int win_len,
+__global__ __launch_bounds__(STAGE_BLOCK) void td_len_iota_kernel(const int64_t* __restrict__ offs, int64_t n,
                                                                     uint32_t* __restrict__ keys, int32_t* __restrict__ vals)
 {
 	const int64_t i = (int64_t)blockIdx.x * STAGE_BLOCK + threadIdx.x;
 	if (i >= n) return;
-	int len = (int)(offs[i + 1] - offs[i]);
-	if (win_len > 0) {
-		const int e = len < win_start + win_len ? len : win_start + win_len;
-		len = e > win_start ? e - win_start : 0;
-	}
-	keys[i] = (uint32_t)len;
+	keys[i] = (uint32_t)(offs[i + 1] - offs[i]);
 	vals[i] = (int32_t)i;
 }
 
@@ -47,12 +42,12 @@ size_t td_stage_sort_temp_bytes(int64_t n_reads, int lmax)
 	return bytes ? bytes : 256;
 }
 
-hipError_t td_stage_sort(const int64_t* offs, int64_t n, int lmax, int win_start, int win_len, int32_t* read_at, uint32_t* keys,
-                         uint32_t* keys_alt, int32_t* vals_alt, void* temp, size_t temp_bytes, hipStream_t stream)
+hipError_t td_stage_sort(const int64_t* offs, int64_t n, int lmax, int32_t* read_at, uint32_t* keys, uint32_t* keys_alt,
+                         int32_t* vals_alt, void* temp, size_t temp_bytes, hipStream_t stream)
 {
 	if (n <= 0) return hipSuccess;
 	const unsigned blocks = (unsigned)((n + STAGE_BLOCK - 1) / STAGE_BLOCK);
-	hipLaunchKernelGGL(td_len_iota_kernel, dim3(blocks), dim3(STAGE_BLOCK), 0, stream, offs, n, win_start, win_len, keys, vals_alt);
+	hipLaunchKernelGGL(td_len_iota_kernel, dim3(blocks), dim3(STAGE_BLOCK), 0, stream, offs, n, keys, vals_alt);
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return e;
 	// LSD radix sort is stable: reads of one length keep the caller's order
@@ -89,11 +84,6 @@ __global__ __launch_bounds__(STAGE_BLOCK) void td_pack_kernel(const TdStageBatch
 		const int64_t o = b.offs[i];
 		len = (int)(b.offs[i + 1] - o);
 		src = b.raw + o;
-		if (b.win_len > 0) {   // do_label_thread / do_probability_estimation decode seq + matchstart for matchend - matchstart bases
-			const int e = len < b.win_start + b.win_len ? len : b.win_start + b.win_len;
-			len = e > b.win_start ? e - b.win_start : 0;
-			src += b.win_start;
-		}
 	}
 	uint32_t* pk = b.packed + (int64_t)tile * (b.nw2 + b.nw1) * TD_WAVE;
 	for (int c = wv; c < b.nw1; c += STAGE_BLOCK / TD_WAVE) {

@@ -34,3 +34,9 @@ def golden(request):
     d = load_golden(request.param)
     d["name"] = request.param
     return d
+
+
+def golden_window(g):
+    """(matchstart, matchend) of a fixture that was run with -start / -end, else None."""
+    ms, me = int(g.get("matchstart", -1)), int(g.get("matchend", -1))
+    return (ms, me) if (ms != -1 or me != -1) else None

@@ -376,6 +376,26 @@ def scenarios(tmp):
         return fq, ["-seed", "42", "-dust", "30", "-1", "B:" + ",".join(bars), "-2", "R:N"]
     sc["dust_b_r"] = dust
 
+    def window():  # -start / -end: the architecture sits in a window of the read; -Q given (calibration with a window is undefined)
+        fq = os.path.join(tmp, "win.fq")
+        rng = np.random.RandomState(37)
+        bars = read_tags(os.path.join(dev, "EDITTAG_4nt_ed_2.txt"), 6)
+        with open(fq, "w") as fh:
+            for i in range(260):
+                pre = "".join("ACGT"[k] for k in rng.randint(0, 4, 5))
+                ins = "".join("ACGT"[k] for k in rng.randint(0, 4, int(rng.randint(30, 52))))
+                post = "".join("ACGT"[k] for k in rng.randint(0, 4, int(rng.randint(14, 40))))
+                body = mutate(rng, bars[rng.randint(len(bars))], 0.03, 0.02) + ins
+                if i % 7 == 0:
+                    body = "".join("ACGT"[k] for k in rng.randint(0, 4, len(body)))
+                if i % 11 == 0:
+                    body = bars[rng.randint(len(bars))] + "A" * 50          # low-complexity insert
+                s_ = (pre + body + post)
+                s_ = s_ + "".join("ACGT"[k] for k in rng.randint(0, 4, max(0, 62 - len(s_))))
+                fh.write("@READ%d\n%s\n+\n%s\n" % (i, s_, "I" * len(s_)))
+        return fq, ["-Q", "5", "-start", "5", "-end", "61", "-dust", "30", "-1", "B:" + ",".join(bars), "-2", "R:N"]
+    sc["window_b_r"] = window
+
     def artifacts():  # -ref: artifact matching between extraction and DUST, 3 threads (4-groups + left-over reads)
         fq = os.path.join(tmp, "art.fq")
         fa = os.path.join(tmp, "art.fa")

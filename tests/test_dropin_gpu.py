@@ -52,7 +52,7 @@ def _outputs(d, prefix):
 
 
 @pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built (need the build container's `make -C oracle ref`)")
-@pytest.mark.parametrize("name", ["c2_b4_r", "c3_b6_s_r_p", "scen2_endloss", "umi_f_s_r", "b_r_s_r", "dust_b_r"])
+@pytest.mark.parametrize("name", ["c2_b4_r", "c3_b6_s_r_p", "scen2_endloss", "umi_f_s_r", "b_r_s_r", "dust_b_r", "window_b_r"])
 def test_reference_cli_with_gpu_run_phmm_writes_identical_files(tmp_path, name):
     g = load_golden(name)
     fq = str(tmp_path / "in.fq")

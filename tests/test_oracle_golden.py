@@ -2,7 +2,7 @@
 (tests/golden/*.npz, produced by tests/golden/make_golden.py through oracle/_ref/ref_dump_rtest)."""
 import numpy as np
 
-from conftest import golden_artifacts
+from conftest import golden_artifacts, golden_window
 from oracle import pyoracle
 
 
@@ -25,7 +25,7 @@ def test_oracle_bit_exact_vs_reference(golden):
     res, labels, seq_after = pyoracle.label_batch(model, g["seq"], g["offs"], float(g["threshold"]),
                                                   minlen=int(g["minlen"]), dust=int(g["dust"]),
                                                   n_threads=art[3] if art else 2,
-                                                  artifacts=art[:3] if art else None)
+                                                  artifacts=art[:3] if art else None, window=golden_window(g))
     assert np.array_equal(_bits(res["b_score"]), _bits(g["b_score"]))
     assert np.array_equal(_bits(res["f_score"]), _bits(g["f_score"]))
     assert np.array_equal(_bits(res["r_score"]), _bits(g["r_score"]))
@@ -42,8 +42,8 @@ def test_oracle_bit_exact_vs_reference(golden):
 def test_oracle_thread_split_is_partition_independent(golden):
     g = golden
     model = pyoracle.OracleModel(g)
-    a = pyoracle.label_batch(model, g["seq"], g["offs"], float(g["threshold"]), int(g["minlen"]), int(g["dust"]), 1)
-    b = pyoracle.label_batch(model, g["seq"], g["offs"], float(g["threshold"]), int(g["minlen"]), int(g["dust"]), 5)
+    a = pyoracle.label_batch(model, g["seq"], g["offs"], float(g["threshold"]), int(g["minlen"]), int(g["dust"]), 1, window=golden_window(g))
+    b = pyoracle.label_batch(model, g["seq"], g["offs"], float(g["threshold"]), int(g["minlen"]), int(g["dust"]), 5, window=golden_window(g))
     assert a[0].tobytes() == b[0].tobytes()
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
 

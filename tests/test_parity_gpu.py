@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_golden, golden_artifacts, GOLDEN_NAMES
+from conftest import load_golden, golden_artifacts, golden_window, GOLDEN_NAMES
 
 pytestmark = pytest.mark.gpu
 
@@ -38,10 +38,15 @@ def _run(ctx, g, seq=None, offs=None, threshold=None):
         ctx.set_artifacts(None)
     ctx.upload_model(g)
     ctx.set_params(float(g["threshold"]) if threshold is None else threshold, int(g["minlen"]), int(g["dust"]))
-    ctx.upload_batch(g["seq"] if seq is None else seq, g["offs"] if offs is None else offs)
-    ctx.counts_reset()
-    ctx.run()
-    return ctx.download()
+    win = golden_window(g) if seq is None else None        # a fixture run with -start / -end
+    ctx.set_window(*(win or (-1, -1)))
+    try:
+        ctx.upload_batch(g["seq"] if seq is None else seq, g["offs"] if offs is None else offs)
+        ctx.counts_reset()
+        ctx.run()
+        return ctx.download()
+    finally:
+        ctx.set_window(-1, -1)
 
 
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
@@ -374,13 +379,14 @@ def test_arch_scores_one_launch_for_all_candidates():
         c.close()
 
 
-def test_start_end_window_scores(ctx):
-    """-start / -end: do_probability_estimation decodes seq + matchstart for matchend - matchstart bases
-    (barcode_hmm.c:2195-2210).  With td_set_window the device cuts the reads itself; the scores must equal the oracle's on
-    the cut reads, bit for bit, for uniform and ragged batches (a read that ends inside the window is scored on what it
-    has there); label mode is refused."""
+def test_start_end_window_against_oracle(ctx):
+    """-start / -end: do_label_thread / do_probability_estimation decode seq + matchstart for matchend - matchstart bases
+    (barcode_hmm.c:2195-2210, :2290-2313) and the rewrite then walks the whole read (:3325-3356).  With td_set_window the
+    device does the same in every mode; results equal the oracle's window path (itself pinned by the reference fixture
+    window_b_r) bit for bit, for uniform and ragged batches -- a read that ends inside the window is decoded on what it has
+    there (the reference's behaviour for such reads is undefined)."""
     from oracle import pyoracle
-    from tagdust_amd import MODE_GET_PROB, MODE_ARCH_COMP, TdError
+    from tagdust_amd import MODE_GET_PROB, MODE_ARCH_COMP
     g = load_golden("c2_b4_r")
     om = pyoracle.OracleModel(g)
     rng = np.random.RandomState(21)
@@ -389,30 +395,35 @@ def test_start_end_window_scores(ctx):
         lens = rng.randint(40, 101, n) if ragged else np.full(n, 100)
         offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         seq = rng.randint(0, 4, int(offs[-1])).astype(np.uint8)
+        seq[rng.random_sample(len(seq)) < 0.004] = 4
         src = g["offs"]
         for i in range(0, n, 2):
             k = i % int(g["n_reads"])
             s_ = g["seq"][src[k]:src[k + 1]][:lens[i] - 3]
             seq[offs[i] + 3:offs[i] + 3 + len(s_)] = s_                     # the architecture starts at base 3
         start, end = 3, 63
-        cut = [seq[offs[i] + start:offs[i] + min(lens[i], end)] for i in range(n)]
-        coffs = np.concatenate([[0], np.cumsum([len(c_) for c_ in cut])]).astype(np.int64)
-        ores, _, _ = pyoracle.label_batch(om, np.concatenate(cut), coffs, float(g["threshold"]), 16, 100, 8)
+        ores, olab, oseq = pyoracle.label_batch(om, seq, offs, float(g["threshold"]), 16, 100, 8, window=(start, end))
+        assert len(set(ores["read_type"].tolist())) >= 2
         ctx.upload_model(g)
         ctx.set_params(float(g["threshold"]), 16, 100)
         ctx.set_window(start, end)
         try:
             ctx.upload_batch(seq, offs)
-            ctx.run(MODE_GET_PROB)
-            res, _, _ = ctx.download(labels=False, seq=False)
+            ctx.run()
+            res, labels, seq_after = ctx.download()
             for k in ("b_score", "f_score", "r_score", "bar_prob"):
                 assert np.array_equal(_bits(res[k]), _bits(ores[k])), (k, ragged)
             assert np.allclose(res["mapq"], ores["Q"], rtol=0, atol=Q_TOL)
+            assert np.array_equal(labels, olab), ragged
+            for k in ("read_type", "barcode", "fingerprint"):
+                assert np.array_equal(res[k], ores[k]), (k, ragged)
+            assert np.array_equal(seq_after, oseq), ragged
+            ctx.run(MODE_GET_PROB)
+            res2, _, _ = ctx.download(labels=False, seq=False)
+            assert np.array_equal(_bits(res2["f_score"]), _bits(ores["f_score"])) and np.allclose(res2["mapq"], ores["Q"], rtol=0, atol=Q_TOL)
             ctx.run(MODE_ARCH_COMP)
-            res, _, _ = ctx.download(labels=False, seq=False)
-            assert np.array_equal(_bits(res["b_score"]), _bits(ores["b_score"]))
-            with pytest.raises(TdError, match="window"):
-                ctx.run()
+            res3, _, _ = ctx.download(labels=False, seq=False)
+            assert np.array_equal(_bits(res3["b_score"]), _bits(ores["b_score"]))
         finally:
             ctx.set_window(-1, -1)
     ctx.upload_batch(g["seq"], g["offs"])          # back to whole reads
