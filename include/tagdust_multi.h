@@ -44,6 +44,7 @@ td_ctx* td_multi_ctx(td_multi* m, int32_t k);          /* the k-th device's cont
 /* replicate model / parameters / artifact sequences on every device (uploads and kernel compiles run concurrently) */
 int  td_multi_model_upload(td_multi* m, const td_model_desc* model);
 int  td_multi_set_params(td_multi* m, float threshold, int32_t minlen, int32_t dust);
+int  td_multi_set_window(td_multi* m, int32_t matchstart, int32_t matchend);   /* -start / -end on every device (td_set_window) */
 int  td_multi_set_artifacts(td_multi* m, const uint8_t* string, const int32_t* s_index, int32_t n_seq,
                             int32_t filter_error, int32_t n_threads);
 /* One run_pHMM call over all devices: reads [0, n) are split with td_shard_bounds, every device runs td_submit / td_wait

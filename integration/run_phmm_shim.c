@@ -213,7 +213,8 @@ int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, s
 	if (upload_model(mb, param, 1) != TD_OK) goto ERROR;
 	if ((g_multi ? td_multi_set_params(g_multi, param->confidence_threshold, param->minlen, param->dust)
 	             : td_set_params(g_ctx, param->confidence_threshold, param->minlen, param->dust)) != TD_OK) goto ERROR;
-	if (td_set_window(g_ctx, windowed ? param->matchstart : -1, windowed ? param->matchend : -1) != TD_OK) goto ERROR;
+	if ((g_multi ? td_multi_set_window(g_multi, windowed ? param->matchstart : -1, windowed ? param->matchend : -1)
+	             : td_set_window(g_ctx, windowed ? param->matchstart : -1, windowed ? param->matchend : -1)) != TD_OK) goto ERROR;
 	/* -ref: match_to_reference (barcode_hmm.c:2349-2351) moves to the device; it only runs in label mode */
 	if (mode == MODE_GET_LABEL && reference_fasta && param->reference_fasta) {
 		if ((g_multi ? td_multi_set_artifacts(g_multi, reference_fasta->string, reference_fasta->s_index, reference_fasta->numseq,
@@ -235,13 +236,13 @@ int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, s
 	int8_t* want_labels = mode == MODE_GET_LABEL ? labels : NULL;
 	uint8_t* want_seq = mode == MODE_GET_LABEL ? seq_out : NULL;
 	int failed;
-	if (g_multi && !windowed)   /* (a window is applied by one context; td_multi has no window call) -- the batch split over the devices like run_pHMM splits it over threads, results in input order */
+	if (g_multi)   /* the batch split over the devices like run_pHMM splits it over threads, results in input order */
 		failed = td_multi_decode(g_multi, codes, 0, offs, numseq, tdmode, res, want_labels, want_seq) != TD_OK;
 	else
 		failed = td_batch_upload(g_ctx, codes, offs, numseq) != TD_OK || td_run(g_ctx, tdmode) != TD_OK ||
 		         td_batch_download(g_ctx, res, want_labels, want_seq) != TD_OK;
 	if (failed) {
-		if (g_multi && !windowed) fprintf(stderr, "tagdust_hip: %s\n", td_multi_last_error(g_multi));
+		if (g_multi) fprintf(stderr, "tagdust_hip: %s\n", td_multi_last_error(g_multi));
 		status = kslFAIL;
 	} else {
 		for (i = 0; i < numseq; i++) {

@@ -177,6 +177,13 @@ extern "C" int td_multi_set_params(td_multi* m, float threshold, int32_t minlen,
 	return TD_OK;
 }
 
+extern "C" int td_multi_set_window(td_multi* m, int32_t matchstart, int32_t matchend)
+{
+	if (!m) return TD_FAIL;
+	for (td_ctx* c : m->ctx) if (td_set_window(c, matchstart, matchend) != TD_OK) return mfail(m, "%s", td_last_error(c));
+	return TD_OK;
+}
+
 extern "C" int td_multi_set_artifacts(td_multi* m, const uint8_t* string, const int32_t* s_index, int32_t n_seq, int32_t filter_error, int32_t n_threads)
 {
 	if (!m) return TD_FAIL;

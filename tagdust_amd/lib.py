@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "td_submit", "td_wait", "td_host_alloc", "td_host_free", "td_set_batch_window", "td_set_window", "td_arch_scores",
 ]
 MULTI_ABI_SYMBOLS = ["td_shard_bounds", "td_count_outcomes", "td_multi_create", "td_multi_destroy", "td_multi_last_error",
-                     "td_multi_size", "td_multi_ctx", "td_multi_model_upload", "td_multi_set_params", "td_multi_set_artifacts",
+                     "td_multi_size", "td_multi_ctx", "td_multi_model_upload", "td_multi_set_params", "td_multi_set_window", "td_multi_set_artifacts",
                      "td_multi_decode", "td_multi_counts", "td_multi_counts_reset", "td_multi_uses_rccl"]
 IO_ABI_SYMBOLS = ["td_io_last_error", "td_reads_parse", "td_reads_free", "td_writer_open", "td_writer_write", "td_writer_close",
                   "td_fasta_parse", "td_fasta_free"]
@@ -131,6 +131,7 @@ def load_library():
     lib.td_multi_ctx.restype = C.c_void_p
     lib.td_multi_model_upload.argtypes = [C.c_void_p, C.POINTER(_ModelDesc)]
     lib.td_multi_set_params.argtypes = [C.c_void_p, C.c_float, C.c_int32, C.c_int32]
+    lib.td_multi_set_window.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.td_multi_set_artifacts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.td_multi_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.td_multi_counts.argtypes = [C.c_void_p, C.c_void_p]
@@ -627,6 +628,9 @@ class TagdustMulti:
         a = np.ascontiguousarray(string, np.uint8)
         ix = np.ascontiguousarray(s_index, np.int32)
         self._chk(self.lib.td_multi_set_artifacts(self.h, a.ctypes.data, ix.ctypes.data, len(ix) - 1, int(filter_error), int(n_threads)))
+
+    def set_window(self, matchstart=-1, matchend=-1):
+        self._chk(self.lib.td_multi_set_window(self.h, int(matchstart), int(matchend)))
 
     def decode(self, bases, offs, mode=MODE_GET_LABEL, labels=True, seq=True, ascii=False):
         bases = np.ascontiguousarray(bases, np.uint8)

@@ -168,7 +168,7 @@ def test_reference_cli_with_artifact_filter(tmp_path, threads):
 
 
 @pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built")
-@pytest.mark.parametrize("name,extra", [("artifacts_b_r", ["-t", "3"]), ("c3_b6_s_r_p", []), ("c2_indel_varlen", ["-t", "5"])])
+@pytest.mark.parametrize("name,extra", [("artifacts_b_r", ["-t", "3"]), ("c3_b6_s_r_p", []), ("c2_indel_varlen", ["-t", "5"]), ("window_b_r", [])])
 def test_reference_cli_over_several_contexts(tmp_path, name, extra):
     """TAGDUST_HIP_DEVICES: the shim hands every batch to td_multi_decode, which splits it like run_pHMM splits it over
     threads and merges in input order.  With one physical GPU the list names device 0 three times (three contexts, host sum

@@ -5,7 +5,7 @@ distinct devices and is exercised by the driver's multi-GPU runs only)."""
 import numpy as np
 import pytest
 
-from conftest import load_golden, golden_artifacts
+from conftest import load_golden, golden_artifacts, golden_window
 
 pytestmark = pytest.mark.gpu
 
@@ -19,6 +19,7 @@ def _single(g, seq, offs):
             c.set_artifacts(art[0], art[1], art[2], art[3])
         c.upload_model(g)
         c.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+        c.set_window(*(golden_window(g) or (-1, -1)))
         c.upload_batch(seq, offs)
         c.counts_reset()
         c.run()
@@ -28,7 +29,7 @@ def _single(g, seq, offs):
 
 
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]], ids=["N1", "N2-same-device", "N3-same-device"])
-@pytest.mark.parametrize("name", ["c3_b6_s_r_p", "artifacts_b_r", "c2_indel_varlen"])
+@pytest.mark.parametrize("name", ["c3_b6_s_r_p", "artifacts_b_r", "c2_indel_varlen", "window_b_r"])
 def test_multi_equals_single_context(name, devices):
     from tagdust_amd.lib import TagdustMulti
     g = load_golden(name)
@@ -41,6 +42,7 @@ def test_multi_equals_single_context(name, devices):
             m.set_artifacts(art[0], art[1], art[2], art[3])
         m.upload_model(g)
         m.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+        m.set_window(*(golden_window(g) or (-1, -1)))
         m.counts_reset()
         res, lab, seq = m.decode(g["seq"], g["offs"])
         cnt = m.counts()
