@@ -150,9 +150,8 @@ int td_set_params(td_ctx* ctx, float threshold, int32_t minlen, int32_t dust);
 /* ---- batches ---- */
 /* Stage a batch of reads: codes = base codes 0..4 (A,C,G,T,other: src/nuc_code.c:46-74) of all reads
  * concatenated, offs[n_reads+1] the read boundaries (like ri[i]->seq / ri[i]->len; read i is codes[offs[i] .. offs[i+1])).
- * One host-to-device
- * copy of the bytes as they are; sorting by length and packing to 2 bit + N mask happen on the device.  Replaces
- * whatever batch was resident; returns when the caller's buffers may be reused. */
+ * One host-to-device copy of the bytes as they are; sorting by length and packing to 2 bit + N mask happen on the device.
+ * Replaces whatever batch was resident; returns when the caller's buffers may be reused. */
 int td_batch_upload(td_ctx* ctx, const uint8_t* codes, const int64_t* offs, int64_t n_reads);
 /* Same from ASCII FASTQ sequence lines (applies the nuc_code mapping). */
 int td_batch_upload_ascii(td_ctx* ctx, const char* bases, const int64_t* offs, int64_t n_reads);
@@ -170,8 +169,8 @@ int td_batch_download(td_ctx* ctx, td_read_result* res, int8_t* labels, uint8_t*
 
 /* ---- pipelined batches: one run_pHMM call per batch (barcode_hmm.c:322), several batches in flight ---- */
 /* Hand over a batch and name where its results go; returns once the reads have left the caller's buffers (they may be
- * reused) with the upload, the decode kernel (mode as td_run; parameters, model and artifact filter as set at this
- * moment) and the download queued on the device.  bases: base codes 0..4, or FASTQ sequence text when is_ascii != 0.
+ * reused) with the upload, the decode kernel (mode as td_run; parameters, model, window and artifact filter as set at
+ * this moment) and the device-side reordering of its results queued; td_wait issues the download when they are ready.  bases: base codes 0..4, or FASTQ sequence text when is_ascii != 0.
  * res / labels / seq_out as in td_batch_download (any may be NULL); they are complete after td_wait(ticket).  offs[0]
  * need not be 0: read i is bases[offs[i] .. offs[i+1]) and output positions count from offs[0] (seq_out + offs[i] - offs[0],
  * labels + offs[i] - offs[0] + i), so a contiguous range of a larger batch can be handed over with its own offsets.
@@ -192,7 +191,8 @@ void  td_host_free(void* p);
  * src/barcode_hmm.c:2111-2148).  Here: the reads are staged once, every candidate's tables go to HBM, and ONE launch of
  * the generic kernel (no per-candidate compile) scores all of them -- the launch's second grid dimension is the
  * candidate.  b_scores[k * n_reads + i] = backward score of read i under models[k] (mb->b_score), in the caller's
- * order.  The context's own model, parameters and counters are untouched; its resident batch is replaced. */
+ * order.  The context's own model, parameters and counters are untouched; its resident batch is replaced.  Whole reads are
+ * scored: a window set with td_set_window is not applied here. */
 int td_arch_scores(td_ctx* ctx, const td_model_desc* const* models, int32_t n_models, const uint8_t* codes,
                    const int64_t* offs, int64_t n_reads, float* b_scores /* [n_models][n_reads] */);
 
