@@ -189,6 +189,7 @@ static int ensure(td_ctx* c, T** p, size_t* cap, size_t bytes)
 	if (bytes == 0) bytes = 256;
 	HIPCHK(c, hipMalloc((void**)p, bytes));
 	*cap = bytes;
+	if (getenv("TD_DEBUG_ALLOC") && bytes > (1u << 30)) fprintf(stderr, "tagdust_hip: hipMalloc(%zu) = %p\n", bytes, (void*)*p);
 	return TD_OK;
 }
 
