@@ -51,6 +51,10 @@ void td_arch_free(td_arch* arch);
 
 /* Statistics over the first <= 1 000 001 reads of a file (base codes 0..4, offsets like td_batch_upload). */
 int  td_sequence_stats(const td_arch* arch, const uint8_t* codes, const int64_t* offs, int64_t n_reads, td_seq_stats* out);
+/* the same for a run with -start / -end (param->matchstart / matchend; -1, -1 = none): the average length becomes the
+ * window's (io.c:258-260) */
+int  td_sequence_stats_window(const td_arch* arch, const uint8_t* codes, const int64_t* offs, int64_t n_reads,
+                              int32_t matchstart, int32_t matchend, td_seq_stats* out);
 
 /* sequencer_error_rate = param->sequencer_error_rate (-e, default 0.05; forced to 0.05 by calibration, calibrateQ.c:65),
  * indel_frequency = param->indel_frequency (-i, default 0.1) */

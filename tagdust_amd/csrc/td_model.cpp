@@ -260,6 +260,18 @@ extern "C" int td_sequence_stats(const td_arch* a, const uint8_t* codes, const i
 	return sequence_stats_limit(a, codes, offs, n_reads, ssi, 1000001);
 }
 
+// with -start / -end the average length is the window's (io.c:258-260); everything else is taken over the whole reads
+extern "C" int td_sequence_stats_window(const td_arch* a, const uint8_t* codes, const int64_t* offs, int64_t n_reads,
+                                        int32_t matchstart, int32_t matchend, td_seq_stats* ssi)
+{
+	if (td_sequence_stats(a, codes, offs, n_reads, ssi) != TD_OK) return TD_FAIL;
+	if (matchstart != -1 || matchend != -1) {
+		// (matchend - matchstart) * total_read / total_read, rounded like every average (io.c:259-261)
+		ssi->average_length = (int)floor((double)(matchend - matchstart) + 0.5);
+	}
+	return TD_OK;
+}
+
 static int sequence_stats_limit(const td_arch* a, const uint8_t* codes, const int64_t* offs, int64_t n_reads, td_seq_stats* ssi, int64_t scan_limit)
 {
 	if (!a || !codes || !offs || !ssi || n_reads < 0) return TD_FAIL;

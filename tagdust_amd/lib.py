@@ -27,7 +27,7 @@ MULTI_ABI_SYMBOLS = ["td_shard_bounds", "td_count_outcomes", "td_multi_create", 
                      "td_multi_decode", "td_multi_counts", "td_multi_counts_reset", "td_multi_uses_rccl"]
 IO_ABI_SYMBOLS = ["td_io_last_error", "td_reads_parse", "td_reads_free", "td_writer_open", "td_writer_write", "td_writer_close",
                   "td_fasta_parse", "td_fasta_free"]
-MODEL_ABI_SYMBOLS = ["td_arch_parse", "td_arch_free", "td_sequence_stats", "td_model_build", "td_model_tables_free",
+MODEL_ABI_SYMBOLS = ["td_arch_parse", "td_arch_free", "td_sequence_stats", "td_sequence_stats_window", "td_model_build", "td_model_tables_free",
                      "td_calibration_emit", "td_calibration_select", "td_calibration_free", "td_estimate_threshold",
                      "td_compare_architectures", "td_simreads", "td_text_free"]
 
@@ -147,6 +147,7 @@ def load_library():
     lib.td_arch_free.argtypes = [C.c_void_p]
     lib.td_arch_free.restype = None
     lib.td_sequence_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(_SeqStats)]
+    lib.td_sequence_stats_window.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(_SeqStats)]
     lib.td_model_build.argtypes = [C.c_void_p, C.POINTER(_SeqStats), C.c_float, C.c_float, C.POINTER(C.c_void_p)]
     lib.td_model_tables_free.argtypes = [C.c_void_p]
     lib.td_model_tables_free.restype = None
@@ -195,7 +196,7 @@ def make_model_desc(md):
     return d, a
 
 
-def build_model(segments, codes, offs, e=0.05, d=0.1, stats_override=None):
+def build_model(segments, codes, offs, e=0.05, d=0.1, stats_override=None, window=None):
     """Host model construction through the C library (include/tagdust_model.h; no GPU needed):
     td_arch_parse -> td_sequence_stats -> td_model_build.  segments: ["B:ACGT,...", "R:N", ...].
     Returns (model mapping with the golden-fixture keys, stats dict)."""
@@ -208,7 +209,8 @@ def build_model(segments, codes, offs, e=0.05, d=0.1, stats_override=None):
         codes = np.ascontiguousarray(codes, np.uint8)
         offs = np.ascontiguousarray(offs, np.int64)
         st = _SeqStats()
-        if lib.td_sequence_stats(arch, codes.ctypes.data, offs.ctypes.data, len(offs) - 1, C.byref(st)) != 0:
+        ms, me = window if window else (-1, -1)
+        if lib.td_sequence_stats_window(arch, codes.ctypes.data, offs.ctypes.data, len(offs) - 1, int(ms), int(me), C.byref(st)) != 0:
             raise TdError("td_sequence_stats failed")
         if stats_override:
             for k, v in stats_override.items():

@@ -9,7 +9,7 @@ from conftest import load_golden, GOLDEN_NAMES
 from tagdust_amd import lib as tdlib
 from test_model_builder import _segments
 
-CALIBRATED = [n for n in GOLDEN_NAMES if n != "short_q_given"]   # that one was run with -Q (no calibration)
+CALIBRATED = [n for n in GOLDEN_NAMES if n not in ("short_q_given", "window_b_r")]   # those were run with -Q (no calibration)
 
 
 @pytest.mark.parametrize("name", CALIBRATED)

@@ -4,6 +4,7 @@ building the model must reproduce init_model_bag()'s tables bit for bit (tests/g
 reference built)."""
 import numpy as np
 
+from conftest import golden_window
 from tagdust_amd import lib as tdlib
 
 
@@ -25,7 +26,7 @@ def _segments(g):
 
 def test_sequence_stats_match_reference(golden):
     g = golden
-    _, st = tdlib.build_model(_segments(g), g["seq"], g["offs"], float(g["e"]), float(g["d"]))
+    _, st = tdlib.build_model(_segments(g), g["seq"], g["offs"], float(g["e"]), float(g["d"]), window=golden_window(g))
     assert np.array_equal(np.array(st["background"]), g["ssi_background"])
     for k in ("expected_5_len", "expected_3_len", "mean_5_len", "stdev_5_len", "mean_3_len", "stdev_3_len", "average_length"):
         assert st[k] == float(g["ssi_" + k]), k
@@ -34,7 +35,7 @@ def test_sequence_stats_match_reference(golden):
 def test_model_tables_match_reference(golden):
     g = golden
     # the reference inflates max_seq_len during calibration only; it does not enter any table
-    md, _ = tdlib.build_model(_segments(g), g["seq"], g["offs"], float(g["e"]), float(g["d"]))
+    md, _ = tdlib.build_model(_segments(g), g["seq"], g["offs"], float(g["e"]), float(g["d"]), window=golden_window(g))
     for k in ("S", "H", "C", "avg_len"):
         assert int(md[k]) == int(g[k]), k
     for k in ("n_hmm", "n_col", "seg_type", "label"):
