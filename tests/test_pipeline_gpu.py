@@ -138,3 +138,44 @@ def test_submit_prob_mode_and_partial_outputs():
         assert np.allclose(res["mapq"], g["mapq"], rtol=0, atol=1e-4)
     finally:
         c.close()
+
+
+def test_new_entry_points_report_misuse():
+    """TD_FAIL with a message, never a crash: pipelined calls without a model, bad option / window values, a device that
+    does not exist for the multi-device driver."""
+    from tagdust_amd import TagdustHip, TdError, RESULT_DTYPE
+    from tagdust_amd.lib import TagdustMulti
+    g = load_golden("c2_b4_r")
+    c = TagdustHip(0)
+    try:
+        offs = np.ascontiguousarray(g["offs"], np.int64)
+        seq = np.ascontiguousarray(g["seq"], np.uint8)
+        res = np.zeros(int(g["n_reads"]), RESULT_DTYPE)
+        with pytest.raises(TdError, match="no model"):
+            c.submit(seq, offs, res=res)
+        with pytest.raises(TdError, match="pipeline_depth"):
+            c.set_option("pipeline_depth", 9)
+        with pytest.raises(TdError, match="matchstart"):
+            c.set_window(10, 5)
+        c.upload_model(g)
+        c.set_params(float(g["threshold"]), 16, 100)
+        with pytest.raises(TdError, match="unsupported mode"):
+            c.submit(seq, offs, mode=3, res=res)
+        bad = offs.copy()
+        bad[5] = bad[4] - 1                       # a negative read length
+        with pytest.raises(TdError, match="has length"):
+            c.submit(seq, bad, res=res)
+        t = c.submit(seq, offs, res=res)          # the context still works afterwards
+        c.wait(t)
+        assert np.array_equal(res["read_type"], g["read_type"])
+        with pytest.raises(TdError, match="tickets are outstanding|no batch with ticket"):
+            t2 = c.submit(seq, offs, res=res)
+            try:
+                c.upload_batch(seq, offs)         # synchronous calls are refused while a ticket is out
+            finally:
+                c.wait(t2)
+            c.wait(t2)                            # waiting twice for one ticket is an error too
+    finally:
+        c.close()
+    with pytest.raises(TdError, match="device"):
+        TagdustMulti([0, 99])
