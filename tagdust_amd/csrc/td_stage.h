@@ -46,3 +46,5 @@ hipError_t td_stage_pack(const TdStageBatch& b, hipStream_t stream);
 hipError_t td_stage_art_left(const TdStageBatch& b, hipStream_t stream);
 // SoA / lane-interleaved kernel outputs -> per-read records, rewritten sequences and labels in the caller's order
 hipError_t td_stage_finish(const TdStageBatch& b, hipStream_t stream);
+// memory-side probe of a candidate workspace allocation (milliseconds, best of three passes); see td_stage.hip
+hipError_t td_ws_probe(uint8_t* ws, int64_t slot_bytes, int n_slots, hipStream_t stream, float* ms);

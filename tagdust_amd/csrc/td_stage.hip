@@ -196,3 +196,56 @@ hipError_t td_stage_finish(const TdStageBatch& b, hipStream_t stream)
 	hipLaunchKernelGGL(td_finish_kernel, dim3((unsigned)b.n_tiles), dim3(STAGE_BLOCK), 0, stream, b);
 	return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Workspace placement probe.  The decode kernel streams every wave slot of the workspace to HBM and back; how fast that
+// goes depends on where the driver placed the allocation (one box: 36.9 ... 40.4 ms for the same batch, following the
+// allocation, not the time -- tools/bimodal_probe.py).  This kernel does the memory side alone on a candidate allocation:
+// every wave writes and reads back `pieces` runs of 16 KiB spread evenly over its slot (so the whole footprint and its
+// address translation are touched), 16 B per lane like the spill.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void td_ws_probe_kernel(uint8_t* __restrict__ ws, int64_t slot_bytes, int n_slots, int pieces)
+{
+	const int lane = threadIdx.x & (TD_WAVE - 1);
+	const int slot = blockIdx.x * (512 / TD_WAVE) + (threadIdx.x >> 6);
+	if (slot >= n_slots) return;
+	uint8_t* base = ws + (int64_t)slot * slot_bytes;
+	const int64_t step = ((slot_bytes - 16384) / pieces) & ~(int64_t)255;
+	float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	for (int p = 0; p < pieces; p++) {
+		float4* q = (float4*)(base + p * step);
+		for (int k = 0; k < 16; k++) q[k * TD_WAVE + lane] = make_float4((float)p, (float)k, (float)lane, 1.0f);
+	}
+	for (int p = 0; p < pieces; p++) {
+		const float4* q = (const float4*)(base + p * step);
+		for (int k = 0; k < 16; k++) { const float4 v = q[k * TD_WAVE + lane]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+	}
+	if (acc.x == -1.0f) ((float4*)base)[lane] = acc;   // keep the loads
+}
+
+// best of three timed passes, in milliseconds (a warm-up pass first)
+hipError_t td_ws_probe(uint8_t* ws, int64_t slot_bytes, int n_slots, hipStream_t stream, float* ms)
+{
+	*ms = 0.0f;
+	if (n_slots <= 0 || slot_bytes < (1 << 20)) return hipSuccess;
+	hipEvent_t e0, e1;
+	hipError_t e = hipEventCreate(&e0);
+	if (e != hipSuccess) return e;
+	e = hipEventCreate(&e1);
+	if (e != hipSuccess) { (void)hipEventDestroy(e0); return e; }
+	const int pieces = 48;
+	const unsigned blocks = (unsigned)((n_slots + 7) / 8);
+	float best = 1e30f;
+	for (int rep = 0; rep < 4 && e == hipSuccess; rep++) {
+		(void)hipEventRecord(e0, stream);
+		hipLaunchKernelGGL(td_ws_probe_kernel, dim3(blocks), dim3(512), 0, stream, ws, slot_bytes, n_slots, pieces);
+		(void)hipEventRecord(e1, stream);
+		e = hipEventSynchronize(e1);
+		float t = 0.0f;
+		if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+		if (rep > 0 && t < best) best = t;
+	}
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	*ms = best;
+	return e;
+}
