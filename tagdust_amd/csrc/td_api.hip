@@ -136,6 +136,8 @@ struct td_ctx {
 	int64_t ticket_counter = 0;
 	hipStream_t s_up = nullptr, s_down = nullptr;   // copy streams of the pipelined calls
 	uint8_t* d_ws = nullptr;      size_t cap_ws = 0;  // one workspace for all slots (decode kernels run one after the other)
+	// position pruning tables of the specialised kernel (td_spec_prune_tables), for reads up to prune_lcap bases
+	float* d_prune = nullptr;     int prune_lcap = 0, prune_stride = 0;
 };
 
 // host threads the library may use for its own copies (TD_HOST_THREADS overrides; at most 16)
@@ -266,7 +268,7 @@ extern "C" void td_ctx_destroy(td_ctx* c)
 	if (c->s_up) (void)hipStreamSynchronize(c->s_up);
 	if (c->s_down) (void)hipStreamSynchronize(c->s_down);
 	void* bufs[] = { c->d_hdr, c->d_cols, c->d_hinfo, c->d_pred_off, c->d_pred_idx, c->d_logsum, c->d_counters,
-	                 c->d_ws, c->d_art_text, c->d_art_index };
+	                 c->d_ws, c->d_art_text, c->d_art_index, c->d_prune };
 	for (void* p : bufs) if (p) (void)hipFree(p);
 	for (int k = 0; k < TD_MAX_PIPELINE; k++) slot_release(c->slots[k]);
 	if (c->s_up) (void)hipStreamDestroy(c->s_up);
@@ -461,6 +463,7 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 	// model-specialised kernel: compile now (seconds); a failure is an error, never a silent fallback
 	if (c->spec_mod) { HIPCHK(c, hipModuleUnload(c->spec_mod)); c->spec_mod = nullptr; }
 	c->spec_fn = nullptr; c->spec_ready = false;
+	c->prune_lcap = 0;   // the pruning tables belong to the model
 	if (c->specialize) {
 		// keep what a later recompile needs
 		c->m_skip.assign(m->skip, m->skip + m->S);
@@ -678,6 +681,19 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 		md.n_hmm = c->m_n_hmm.data(); md.n_col = c->m_n_col.data(); md.trans = c->m_trans.data();
 		td_spec_layout(s.slay, &md, s.lmax);
 		slot_bytes = s.slay.slot_bytes;
+		if (s.lmax > c->prune_lcap || !c->d_prune) {
+			// bound tables of the position pruning, for reads up to lcap bases (kernels in flight read the old ones)
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			const int lcap = (s.lmax + 2 + 255) / 256 * 256, stride = lcap + 8;
+			std::vector<float> tab;
+			const int ps = td_spec_prune_segs(&c->m_desc);
+			if (ps > 0) td_spec_prune_tables(&c->m_desc, ps, lcap, stride, tab);
+			else tab.assign((size_t)4 * stride, 0.0f);
+			if (c->d_prune) { HIPCHK(c, hipFree(c->d_prune)); c->d_prune = nullptr; }
+			HIPCHK(c, hipMalloc((void**)&c->d_prune, tab.size() * sizeof(float)));
+			HIPCHK(c, hipMemcpy(c->d_prune, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+			c->prune_lcap = lcap; c->prune_stride = stride;
+		}
 	}
 	// wave slots: enough to fill the chip (2 workgroups of 4 waves per CU share the LDS), bounded by HBM
 	const int wpb = (c->spec_ready ? c->spec_block : td_kernel_block_threads()) / TD_WAVE;
@@ -858,6 +874,7 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 		sa.out_keep = ka.out_keep; sa.out_labels = ka.out_labels; sa.counters = ka.counters;
 		sa.art_text = ka.art_text; sa.art_index = ka.art_index; sa.art_left = ka.art_left; sa.art_n = ka.art_n; sa.art_fe = ka.art_fe;
 		sa.ws = ka.ws; sa.lay = s.slay;
+		sa.prune = c->d_prune; sa.prune_stride = c->prune_stride;
 		size_t sz = sizeof sa;
 		void* cfg[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &sa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END };
 		const int wpb = c->spec_block / TD_WAVE;

@@ -130,7 +130,7 @@ struct TdSpecArgs {
 	float   threshold;
 	int32_t minlen, dust;
 	int32_t win_start, win_len;             // -start / -end window for the DP phases; win_len = 0: whole reads
-	int32_t pad0;
+	int32_t prune_stride;                   // floats per table in `prune`
 	float*   __restrict__ out_f;
 	float*   __restrict__ out_b;
 	float*   __restrict__ out_r;
@@ -149,4 +149,6 @@ struct TdSpecArgs {
 	int32_t art_n, art_fe;
 	uint8_t* __restrict__ ws;
 	TdSpecLayout lay;
+	// position pruning (td_spec_kernel.inc): four host tables of prune_stride floats each -- fb[i], bwb[m], wa[i], wb[i]
+	const float* __restrict__ prune;
 };

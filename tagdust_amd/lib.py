@@ -19,7 +19,7 @@ NUM_COUNTERS = NUM_OUTCOME_SLOTS + NUM_BARCODE_BINS
 ABI_SYMBOLS = [
     "td_ctx_create", "td_ctx_destroy", "td_last_error", "td_logsum_table", "td_model_upload", "td_set_params",
     "td_batch_upload", "td_batch_upload_ascii", "td_run", "td_sync", "td_batch_download", "td_counts_reset",
-    "td_counts_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_batch_info", "td_set_option", "td_get_option", "td_set_artifacts", "td_spec_source",
+    "td_counts_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_batch_info", "td_set_option", "td_get_option", "td_set_artifacts", "td_spec_source", "td_spec_prune_info",
     "td_submit", "td_wait", "td_host_alloc", "td_host_free", "td_set_batch_window", "td_set_window", "td_arch_scores",
 ]
 MULTI_ABI_SYMBOLS = ["td_shard_bounds", "td_count_outcomes", "td_multi_create", "td_multi_destroy", "td_multi_last_error",
@@ -102,6 +102,7 @@ def load_library():
         lib.td_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]
     lib.td_spec_source.argtypes = [C.POINTER(_ModelDesc), C.c_char_p, C.c_int64]
     lib.td_spec_source.restype = C.c_int64
+    lib.td_spec_prune_info.argtypes = [C.POINTER(_ModelDesc), C.c_int32, C.c_void_p, C.POINTER(C.c_float)]
     lib.td_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.td_batch_upload_ascii.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.td_run.argtypes = [C.c_void_p, C.c_int]
@@ -413,6 +414,17 @@ def spec_source(md):
     buf = C.create_string_buffer(int(n) + 1)
     lib.td_spec_source(C.byref(d), buf, int(n) + 1)
     return buf.value.decode()
+
+
+def spec_prune_info(md, lcap):
+    """Position-pruning tables of the specialised kernel for this model: (n_pruned_segments, z, fbm, bwu, wa, wb)."""
+    lib = load_library()
+    d, keep = make_model_desc(md)
+    tab = np.zeros(4 * (lcap + 8), np.float32)
+    z = C.c_float(0)
+    ps = lib.td_spec_prune_info(C.byref(d), int(lcap), tab.ctypes.data, C.byref(z))
+    t = tab.reshape(4, lcap + 8)
+    return int(ps), float(z.value), t[0], t[1], t[2], t[3]
 
 
 class TagdustHip:
