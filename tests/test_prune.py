@@ -1,0 +1,186 @@
+"""Position pruning of the specialised kernel (td_spec_kernel.inc, "Position pruning").
+
+CPU: the host's bound tables -- the only thing the kernel's exactness argument takes from outside -- dominate every DP value
+the oracle (the pinned restatement of the reference) computes, on every fixture and on random architectures.
+GPU: a batch decodes to the same bytes with pruning on and off, the pruned path is the one that ran, and every fall-back
+route (failed check, spill cut too short) gives the same bytes again."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, GOLDEN_NAMES
+
+
+def _margins(md, seq, offs):
+    from oracle import pyoracle
+    from tagdust_amd import lib as tdlib
+    lcap = int(np.diff(offs).max()) + 2
+    ps, z, fb, bwb, wa, wb = tdlib.spec_prune_info(md, lcap)
+    if ps <= 0:
+        return ps, None
+    assert z > 103.98 + np.log(2.0)
+    return ps, pyoracle.bound_margins(pyoracle.OracleModel(md), seq, offs, ps, fb, bwb, wa)
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_bounds_dominate_reference_values(name):
+    """fb[i] >= M/I_forward, bwb[len - i] >= M/I_backward of the pruned segments, wa[i] - 15.75 >= the read segment's entry
+    term, for every read of every reference fixture (the oracle's matrices are the reference's, test_oracle_golden)."""
+    g = load_golden(name)
+    ps, mg = _margins(g, g["seq"], g["offs"])
+    if name in ("casava_index", "o_b_s_r"):
+        assert ps == 0            # a read segment first / an optional segment in front of it: nothing to prune
+        return
+    assert ps >= 1, name
+    assert mg.min() > 0.0, (name, mg)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_bounds_dominate_on_random_architectures(seed):
+    """The same on random segment lists (partial / barcode / fingerprint / spacer / G segments in front of the read
+    segment), models from the library's own builder, reads with substitutions, indels, Ns and unrelated sequences."""
+    from tagdust_amd import lib as tdlib
+    from test_parity_gpu import _random_arch
+    rng = np.random.RandomState(7000 + seed)
+    segs, parts = _random_arch(rng)
+    reads = []
+    for i in range(150):
+        s_ = "".join(p() for p in parts)
+        out = []
+        for ch in s_:
+            u = rng.random_sample()
+            if u < 0.03:
+                out.append("ACGTN"[rng.randint(5)])
+            elif u < 0.04:
+                continue
+            elif u < 0.05:
+                out.append(ch); out.append("ACGT"[rng.randint(4)])
+            else:
+                out.append(ch)
+        s_ = "".join(out)
+        if rng.random_sample() < 0.15 or len(s_) < 12:
+            s_ = "".join("ACGT"[x] for x in rng.randint(0, 4, rng.randint(12, 120)))
+        reads.append(np.array(["ACGTN".index(ch) for ch in s_], np.uint8))
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    seq = np.concatenate(reads)
+    md, _ = tdlib.build_model(segs, seq, offs, 0.05, 0.1)
+    ps, mg = _margins(md, seq, offs)
+    if ps > 0:
+        assert mg.min() > 0.0, (segs, mg)
+
+
+def test_model_section_states_the_pruned_segments():
+    from tagdust_amd import lib as tdlib
+    g = load_golden("c3_b6_s_r_p")
+    src = tdlib.spec_source(g)
+    assert "static constexpr int kPruneSegs = 2;" in src
+    g = load_golden("casava_index")
+    assert "static constexpr int kPruneSegs = 0;" in tdlib.spec_source(g)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _decode(workload, n, env, stats=True):
+    """One resident batch of a bench workload through a fresh context compiled under `env`; (res, labels, seq, counters)."""
+    import bench
+    from tagdust_amd import TagdustHip
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        bench.select_workload(workload)
+        model = bench.load_model()
+        reads, offs = bench.synth_host_batch(n, 77)
+        c = TagdustHip(0)
+        try:
+            c.set_option("poison_workspace", 1)
+            c.upload_model(model)
+            c.set_params(float(model["threshold"]), int(model["minlen"]), int(model["dust"]))
+            c.upload_batch(reads, offs)
+            c.counts_reset()
+            c.run()
+            res, labels, seq = c.download()
+            return res, labels, seq, c.counts()
+        finally:
+            c.close()
+    finally:
+        bench.select_workload("c3")
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _same(a, b):
+    return a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,n", [("c3", 1 << 16), ("c2", 1 << 16), ("c5", 1 << 14)], ids=["config3", "config2", "config5"])
+def test_pruned_equals_dense_and_fallbacks(workload, n):
+    """Same bytes with pruning off, on, and on with each fall-back route forced: the total_prob check failing for every tile
+    (second, dense pass), the spill cut guessed too short (rows missing -> dense pass), a wave giving up after repeated
+    failures.  The statistics counters (TD_SPEC_PRUNE_STATS) show which route ran."""
+    S0 = 8 + 232    # counter slots: decisions, sum of required cuts, spill too short, failed checks, tiles, sum of cuts, dense tiles
+    dense = _decode(workload, n, {"TD_SPEC_PRUNE": "0", "TD_SPEC_PRUNE_STATS": "0"})
+    on = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_STATS": "1"})
+    assert _same(dense, on)
+    st = on[3][S0:S0 + 8]
+    tiles = (n + 63) // 64
+    assert st[4] == tiles and st[6] == 0 and st[2] == 0 and st[3] == 0      # every tile pruned, no second pass
+    assert st[5] / tiles < 0.5 * (100 if workload == "c2" else 150)          # mean cut well inside the read
+    # every tile's total_prob check fails: second pass for the first tiles of a wave, then the wave stops trying
+    forced = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_STATS": "1", "TD_SPEC_EXTRA_OPTS": "-DTDS_PRUNE_TT=1000.0f"})
+    assert _same(dense, forced)
+    st = forced[3][S0:S0 + 8]
+    assert st[3] > 0 and st[6] == st[4] == tiles
+    # spill cut far too short: the exact cut needs rows that were not spilled
+    short = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_STATS": "1", "TD_SPEC_EXTRA_OPTS": "-DTDS_PRUNE_BGAP=-150.0f -DTDS_PRUNE_MARGIN=0"})
+    assert _same(dense, short)
+    st = short[3][S0:S0 + 8]
+    assert st[2] > 0 and st[3] == 0
+
+
+@pytest.mark.gpu
+def test_pruning_on_ragged_short_and_dead_reads():
+    """Tiles whose reads end before, at and after the cut, reads too short for any path (decoded densely), N-rich reads:
+    pruned and dense contexts agree, and both equal the oracle."""
+    from oracle import pyoracle
+    from tagdust_amd import TagdustHip
+    g = load_golden("c3_b6_s_r_p")
+    rng = np.random.RandomState(99)
+    base = [g["seq"][g["offs"][i]:g["offs"][i + 1]] for i in range(len(g["offs"]) - 1)]
+    reads = []
+    for k in range(1500):
+        r = base[rng.randint(len(base))].copy()
+        L = int(rng.choice([12, 20, 30, 34, 35, 36, 37, 40, 60, 100, 150]))
+        r = r[:L] if len(r) >= L else r
+        if rng.random_sample() < 0.1:
+            r[rng.randint(0, len(r), max(1, len(r) // 5))] = 4
+        if rng.random_sample() < 0.1:
+            r = rng.randint(0, 4, len(r)).astype(np.uint8)
+        reads.append(r)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    seq = np.concatenate(reads)
+    outs = []
+    for prune in ("0", "1"):
+        os.environ["TD_SPEC_PRUNE"] = prune
+        try:
+            c = TagdustHip(0)
+            c.set_option("poison_workspace", 1)
+            c.upload_model(g)
+            c.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+            c.upload_batch(seq, offs)
+            c.run()
+            outs.append(c.download())
+            c.close()
+        finally:
+            os.environ.pop("TD_SPEC_PRUNE", None)
+    assert _same(outs[0], outs[1])
+    ores, olab, oseq = pyoracle.label_batch(pyoracle.OracleModel(g), seq, offs, float(g["threshold"]), int(g["minlen"]), int(g["dust"]), 8)
+    res, labels, seq_after = outs[1]
+    for k in ("b_score", "f_score", "r_score", "bar_prob"):
+        assert np.array_equal(res[k].view(np.uint32), ores[k].view(np.uint32)), k
+    assert np.array_equal(labels, olab) and np.array_equal(seq_after, oseq)
+    for k in ("read_type", "barcode", "fingerprint"):
+        assert np.array_equal(res[k], ores[k]), k
