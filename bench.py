@@ -472,8 +472,10 @@ def main():
                          "traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "traffic_source": traffic_note,
                          "note": "algorithmic bytes are tiny; the kernel's real HBM traffic is the backward-row spill "
-                                 "(traffic_gbps), which binds it: that access pattern alone reaches 5.5 TB/s "
-                                 "(tools/ubench/spill_stream.hip, DESIGN.md section 4)"},
+                                 "(traffic_gbps).  With the leading segments pruned by position (DESIGN.md section 4) that spill "
+                                 "no longer binds the kernel (~3 TB/s of the 5.5 TB/s the access pattern alone reaches, "
+                                 "tools/ubench/spill_stream.hip): what binds it now is VALU issue and the latency of the "
+                                 "table-quantised logsum chains the reference's summation order fixes"},
         }
         extra = {}
         if args.extras:
