@@ -123,11 +123,12 @@ int td_get_option(td_ctx* ctx, const char* name, int32_t* value);
 /* The HIP source td_model_upload would compile for this model (no GPU needed).  Returns its length; copies at
  * most cap-1 bytes + NUL into buf when buf != NULL. */
 int64_t td_spec_source(const td_model_desc* model, char* buf, int64_t cap);
-/* Position pruning of the specialised kernel: the number of leading segments whose forward sweep may
- * stop early (0: the model has none), and -- when tab != NULL -- the four bound tables of lcap + 8 floats each the kernel
- * decides with (forward envelope per position, backward envelope per bases to go, the two check thresholds of the first
- * read segment); *z = the zero-posterior margin.  No GPU needed; for inspection and tests. */
-int td_spec_prune_info(const td_model_desc* model, int32_t lcap, float* tab, float* z);
+/* Position pruning of the specialised kernel: *n_seg = the number of leading segments whose forward
+ * sweep may stop early (0: none), *sfx_first = the first trailing segment whose backward sweep may stop early (S: none), and
+ * -- when tab != NULL -- the eight bound tables of lcap + 8 floats each the kernel decides with (forward bound per position,
+ * backward bound per bases to go, the two check thresholds of the adjoining read segment; once for each end); *z = the
+ * zero-posterior margin.  No GPU needed; for inspection and tests. */
+int td_spec_prune_info(const td_model_desc* model, int32_t lcap, float* tab, float* z, int32_t* n_seg, int32_t* sfx_first);
 /* -ref artifact filter, match_to_reference() src/barcode_hmm.c:2478-2583 (runs between extraction and DUST in
  * TD_MODE_GET_LABEL): string / s_index[n_seq+1] are struct fasta's fields as read_fasta() leaves them (io.c:1912-2001:
  * per sequence one 'X' byte followed by the base codes); filter_error = param->filter_error (-fe);

@@ -73,19 +73,20 @@ def lib():
     return _lib
 
 
-def bound_margins(model, seqs, offs, n_seg, fb, bwb, wa):
-    """Smallest margins (forward, backward, entry term) by which the device kernel's pruning bounds dominate the DP values
-    the oracle computes for the first n_seg segments over a batch; negative = a bound is violated."""
+def bound_margins(model, seqs, offs, info):
+    """Smallest margins by which the device kernel's pruning bounds (`info` = tagdust_amd.lib.spec_prune_info()) dominate the DP
+    values the oracle computes over a batch: [forward, backward, entry term] of the leading pruned segments, then [forward,
+    backward, exit term] of the trailing ones (1e30 where a side has nothing pruned); negative = a bound is violated."""
     L = lib()
     L.tdo_bound_margins.restype = C.c_int
-    L.tdo_bound_margins.argtypes = [C.POINTER(_Model), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_int, C.c_void_p]
+    L.tdo_bound_margins.argtypes = [C.POINTER(_Model), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
     offs = np.ascontiguousarray(offs, dtype=np.int64)
-    fb, bwb, wa = (np.ascontiguousarray(a, dtype=np.float32) for a in (fb, bwb, wa))
-    out = np.zeros(3, np.float64)
-    rc = L.tdo_bound_margins(C.byref(model.c), seqs.ctypes.data, offs.ctypes.data, len(offs) - 1, int(n_seg),
-                             fb.ctypes.data, bwb.ctypes.data, wa.ctypes.data, len(fb) - 8, out.ctypes.data)
+    names = ("fb", "bwb", "wa", "wb", "fbs", "bws", "wc", "wd")
+    tab = np.ascontiguousarray(np.stack([info[k] for k in names]), dtype=np.float32)
+    out = np.zeros(6, np.float64)
+    rc = L.tdo_bound_margins(C.byref(model.c), seqs.ctypes.data, offs.ctypes.data, len(offs) - 1, int(info["n_seg"]),
+                             int(info["sfx_first"]), tab.ctypes.data, tab.shape[1], out.ctypes.data)
     if rc != 0:
         raise RuntimeError("tdo_bound_margins failed (%d)" % rc)
     return out

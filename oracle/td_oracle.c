@@ -668,24 +668,28 @@ void tdo_label_read(const tdo_model* m, const tdo_params* p, tdo_workspace* ws,
 
 /* ------------------------------------------------------------------------------------------------
  * Test support for the device kernel's position pruning (tagdust_amd/csrc/td_spec_kernel.inc): the host states
- * read-independent upper bounds on the DP values of the first n_seg segments -- fb[i] on M/I_forward at position i,
- * bwb[k] on M/I_backward with k bases to go, wa[i] - 15.75 on previous_silent[i-1] + silent_to_I of segment n_seg.
+ * read-independent upper bounds on DP values -- for the first n_seg segments fb[i] on M/I_forward at position i, bwb[k]
+ * on M/I_backward with k bases to go, wa[i] - 15.75 on previous_silent[i-1] + silent_to_I of segment n_seg; for the
+ * segments from sfx_first on fbs[i] / bws[k] likewise and wc[k] - 15.75 on P_backward_next[i+1] + ISKIP of segment
+ * sfx_first - 1 with k = len - i - 1.  tab holds the eight tables (fb, bwb, wa, wb, fbs, bws, wc, wd) of `stride` floats.
  * This runs backward() and forward_max_posterior_decoding() as above on every read and returns the smallest margins
  * bound - value it meets (a negative margin is a violated bound); -inf values are skipped.
- * margins[0]: forward, [1]: backward, [2]: entry term of segment n_seg.
+ * margins[0..2]: forward, backward, entry term (leading segments); [3..5]: forward, backward, exit term (trailing).
  * ---------------------------------------------------------------------------------------------- */
-int tdo_bound_margins(const tdo_model* m, const uint8_t* seqs, const int64_t* offs, int64_t n_reads, int n_seg,
-                      const float* fb, const float* bwb, const float* wa, int cap, double* margins)
+int tdo_bound_margins(const tdo_model* m, const uint8_t* seqs, const int64_t* offs, int64_t n_reads, int n_seg, int sfx_first,
+                      const float* tab, int stride, double* margins)
 {
 	int max_len = 1;
 	for (int64_t r = 0; r < n_reads; r++) if (offs[r + 1] - offs[r] > max_len) max_len = (int)(offs[r + 1] - offs[r]);
-	if (max_len > cap || n_seg < 1 || n_seg >= m->S) return -1;
+	if (max_len + 2 > stride || n_seg < 0 || n_seg >= m->S || sfx_first < 1 || sfx_first > m->S) return -1;
+	const float *fb = tab, *bwb = tab + stride, *wa = tab + 2 * stride, *fbs = tab + 4 * stride, *bws = tab + 5 * stride, *wc = tab + 6 * stride;
 	tdo_workspace* ws = tdo_workspace_new(m, max_len);
 	if (!ws) return -1;
 	int8_t* labels = (int8_t*)malloc((size_t)max_len + 2);
-	margins[0] = margins[1] = margins[2] = 1.0e30;
+	for (int k = 0; k < 6; k++) margins[k] = 1.0e30;
 	const int st = ws->stride;
-	const int c_end = m->col_off[n_seg];          /* columns of the first n_seg segments */
+	const int c_end = m->col_off[n_seg];                                      /* columns of the first n_seg segments */
+	const int c_sfx = sfx_first < m->S ? m->col_off[sfx_first] : m->C;       /* first column of the trailing segments */
 	for (int64_t r = 0; r < n_reads; r++) {
 		const uint8_t* seq = seqs + offs[r];
 		const int len = (int)(offs[r + 1] - offs[r]);
@@ -694,19 +698,32 @@ int tdo_bound_margins(const tdo_model* m, const uint8_t* seqs, const int64_t* of
 		const float b = tdo_backward(m, ws, seq, len);
 		if (!(b > NEG_INF)) continue;
 		tdo_forward_decode(m, ws, seq, len, b, &f, &rs, &bp, labels);
-		for (int c = 0; c < c_end; c++) {
+		for (int c = 0; c < m->C; c++) {
+			if (c >= c_end && c < c_sfx) continue;
+			const int o = c < c_end ? 0 : 3;
+			const float* F = c < c_end ? fb : fbs;
+			const float* B = c < c_end ? bwb : bws;
 			for (int i = 1; i <= len; i++) {
 				const float vf[2] = { ws->MF[c * st + i], ws->IF[c * st + i] };
 				const float vb[2] = { ws->MB[c * st + i], ws->IB[c * st + i] };
 				for (int k = 0; k < 2; k++) {
-					if (vf[k] > NEG_INF && (double)fb[i] - vf[k] < margins[0]) margins[0] = (double)fb[i] - vf[k];
-					if (vb[k] > NEG_INF && (double)bwb[len - i] - vb[k] < margins[1]) margins[1] = (double)bwb[len - i] - vb[k];
+					if (vf[k] > NEG_INF && (double)F[i] - vf[k] < margins[o]) margins[o] = (double)F[i] - vf[k];
+					if (vb[k] > NEG_INF && (double)B[len - i] - vb[k] < margins[o + 1]) margins[o + 1] = (double)B[len - i] - vb[k];
 				}
 			}
 		}
-		for (int i = 1; i <= len; i++) {
-			const float pm = ws->SF[(n_seg - 1) * st + (i - 1)] + m->sI[c_end];
-			if (pm > NEG_INF && ((double)wa[i] - 15.75) - pm < margins[2]) margins[2] = ((double)wa[i] - 15.75) - pm;
+		if (n_seg > 0) {
+			for (int i = 1; i <= len; i++) {
+				const float pm = ws->SF[(n_seg - 1) * st + (i - 1)] + m->sI[c_end];
+				if (pm > NEG_INF && ((double)wa[i] - 15.75) - pm < margins[2]) margins[2] = ((double)wa[i] - 15.75) - pm;
+			}
+		}
+		if (sfx_first < m->S) {
+			const float iskip = m->trans[(size_t)m->col_off[sfx_first - 1] * 9 + TDO_ISKIP];
+			for (int i = 1; i < len; i++) {
+				const float pn = ws->SB[sfx_first * st + (i + 1)] + iskip;
+				if (pn > NEG_INF && ((double)wc[len - i - 1] - 15.75) - pn < margins[5]) margins[5] = ((double)wc[len - i - 1] - 15.75) - pn;
+			}
 		}
 	}
 	free(labels);

@@ -138,8 +138,8 @@ int   tdo_label_batch_art(const tdo_model* m, const tdo_params* p, const tdo_art
 
 /* test support for the device kernel's position pruning: smallest margins by which the host's bound tables dominate
  * the DP values of the first n_seg segments over a batch (see td_oracle.c) */
-int   tdo_bound_margins(const tdo_model* m, const uint8_t* seqs, const int64_t* offs, int64_t n_reads, int n_seg,
-                        const float* fb, const float* bwb, const float* wa, int cap, double* margins);
+int   tdo_bound_margins(const tdo_model* m, const uint8_t* seqs, const int64_t* offs, int64_t n_reads, int n_seg, int sfx_first,
+                        const float* tab, int stride, double* margins);
 
 #ifdef __cplusplus
 }

@@ -686,9 +686,9 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 			HIPCHK(c, hipStreamSynchronize(c->stream));
 			const int lcap = (s.lmax + 2 + 255) / 256 * 256, stride = lcap + 8;
 			std::vector<float> tab;
-			const int ps = td_spec_prune_segs(&c->m_desc);
-			if (ps > 0) td_spec_prune_tables(&c->m_desc, ps, lcap, stride, tab);
-			else tab.assign((size_t)4 * stride, 0.0f);
+			const int ps = td_spec_prune_segs(&c->m_desc), sf = td_spec_prune_sfx(&c->m_desc);
+			if (ps > 0 || sf < c->m_desc.S) td_spec_prune_tables(&c->m_desc, ps, sf, lcap, stride, tab);
+			else tab.assign((size_t)TD_PRUNE_TABLES * stride, 0.0f);
 			if (c->d_prune) { HIPCHK(c, hipFree(c->d_prune)); c->d_prune = nullptr; }
 			HIPCHK(c, hipMalloc((void**)&c->d_prune, tab.size() * sizeof(float)));
 			HIPCHK(c, hipMemcpy(c->d_prune, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));

@@ -102,7 +102,7 @@ def load_library():
         lib.td_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]
     lib.td_spec_source.argtypes = [C.POINTER(_ModelDesc), C.c_char_p, C.c_int64]
     lib.td_spec_source.restype = C.c_int64
-    lib.td_spec_prune_info.argtypes = [C.POINTER(_ModelDesc), C.c_int32, C.c_void_p, C.POINTER(C.c_float)]
+    lib.td_spec_prune_info.argtypes = [C.POINTER(_ModelDesc), C.c_int32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.td_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.td_batch_upload_ascii.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.td_run.argtypes = [C.c_void_p, C.c_int]
@@ -417,14 +417,19 @@ def spec_source(md):
 
 
 def spec_prune_info(md, lcap):
-    """Position-pruning tables of the specialised kernel for this model: (n_pruned_segments, z, fbm, bwu, wa, wb)."""
+    """Position-pruning tables of the specialised kernel for this model: dict with n_seg (leading segments pruned, 0 = none),
+    sfx_first (first trailing segment pruned, S = none), z, and the tables fb, bwb, wa, wb, fbs, bws, wc, wd."""
     lib = load_library()
     d, keep = make_model_desc(md)
-    tab = np.zeros(4 * (lcap + 8), np.float32)
-    z = C.c_float(0)
-    ps = lib.td_spec_prune_info(C.byref(d), int(lcap), tab.ctypes.data, C.byref(z))
-    t = tab.reshape(4, lcap + 8)
-    return int(ps), float(z.value), t[0], t[1], t[2], t[3]
+    tab = np.zeros(8 * (lcap + 8), np.float32)
+    z, ns, sf = C.c_float(0), C.c_int32(0), C.c_int32(0)
+    if lib.td_spec_prune_info(C.byref(d), int(lcap), tab.ctypes.data, C.byref(z), C.byref(ns), C.byref(sf)) != 0:
+        raise RuntimeError("td_spec_prune_info failed")
+    t = tab.reshape(8, lcap + 8)
+    out = dict(n_seg=int(ns.value), sfx_first=int(sf.value), S=int(md["S"]), z=float(z.value))
+    for k, name in enumerate(("fb", "bwb", "wa", "wb", "fbs", "bws", "wc", "wd")):
+        out[name] = t[k]
+    return out
 
 
 class TagdustHip:

@@ -16,24 +16,28 @@ def _margins(md, seq, offs):
     from oracle import pyoracle
     from tagdust_amd import lib as tdlib
     lcap = int(np.diff(offs).max()) + 2
-    ps, z, fb, bwb, wa, wb = tdlib.spec_prune_info(md, lcap)
-    if ps <= 0:
-        return ps, None
-    assert z > 103.98 + np.log(2.0)
-    return ps, pyoracle.bound_margins(pyoracle.OracleModel(md), seq, offs, ps, fb, bwb, wa)
+    info = tdlib.spec_prune_info(md, lcap)
+    if info["n_seg"] == 0 and info["sfx_first"] == info["S"]:
+        return info, None
+    assert info["z"] > 103.98 + np.log(2.0)
+    return info, pyoracle.bound_margins(pyoracle.OracleModel(md), seq, offs, info)
 
 
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_bounds_dominate_reference_values(name):
     """fb[i] >= M/I_forward, bwb[len - i] >= M/I_backward of the pruned segments, wa[i] - 15.75 >= the read segment's entry
-    term, for every read of every reference fixture (the oracle's matrices are the reference's, test_oracle_golden)."""
+    term (leading segments), and the same with the exit term for the trailing segments, for every read of every reference
+    fixture (the oracle's matrices are the reference's, test_oracle_golden)."""
     g = load_golden(name)
-    ps, mg = _margins(g, g["seq"], g["offs"])
+    info, mg = _margins(g, g["seq"], g["offs"])
     if name in ("casava_index", "o_b_s_r"):
-        assert ps == 0            # a read segment first / an optional segment in front of it: nothing to prune
-        return
-    assert ps >= 1, name
-    assert mg.min() > 0.0, (name, mg)
+        assert info["n_seg"] == 0     # a read segment first / an optional segment in front of it: nothing to prune in front
+    else:
+        assert info["n_seg"] >= 1, name
+    if name in ("c3_b6_s_r_p", "c5_big_b96_f_r_p", "scen2_p_b_r_p"):
+        assert info["sfx_first"] == info["S"] - 1      # the 3' adapter
+    if mg is not None:
+        assert mg.min() > 0.0, (name, mg)
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -65,8 +69,8 @@ def test_bounds_dominate_on_random_architectures(seed):
     offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
     seq = np.concatenate(reads)
     md, _ = tdlib.build_model(segs, seq, offs, 0.05, 0.1)
-    ps, mg = _margins(md, seq, offs)
-    if ps > 0:
+    info, mg = _margins(md, seq, offs)
+    if mg is not None:
         assert mg.min() > 0.0, (segs, mg)
 
 
@@ -74,7 +78,7 @@ def test_model_section_states_the_pruned_segments():
     from tagdust_amd import lib as tdlib
     g = load_golden("c3_b6_s_r_p")
     src = tdlib.spec_source(g)
-    assert "static constexpr int kPruneSegs = 2;" in src
+    assert "static constexpr int kPruneSegs = 2;" in src and "static constexpr int kSfxFirst = 3;" in src
     g = load_golden("casava_index")
     assert "static constexpr int kPruneSegs = 0;" in tdlib.spec_source(g)
 
@@ -134,11 +138,18 @@ def test_pruned_equals_dense_and_fallbacks(workload, n):
     assert _same(dense, forced)
     st = forced[3][S0:S0 + 8]
     assert st[3] > 0 and st[6] == st[4] == tiles
-    # spill cut far too short: the exact cut needs rows that were not spilled
+    # guessed far too optimistically: the exact cut needs rows the backward sweep did not spill (leading segments) / the exact
+    # stop lies below the position the backward sweep of the trailing segments reached, or the read segment's check fails
     short = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_STATS": "1", "TD_SPEC_EXTRA_OPTS": "-DTDS_PRUNE_BGAP=-150.0f -DTDS_PRUNE_MARGIN=0"})
     assert _same(dense, short)
     st = short[3][S0:S0 + 8]
-    assert st[2] > 0 and st[3] == 0
+    assert st[2] + short[3][8 + 226] > 0 and st[3] == 0 and st[6] == tiles
+    # the trailing segments alone (config 3 and 5 end in a 3' adapter): pruned == dense, the stop lies well inside the read
+    if workload != "c2":
+        sfx = on[3][8 + 224:8 + 228]
+        assert sfx[0] == tiles and sfx[2] == 0 and 30 < sfx[3] / tiles < 140
+        only_sfx = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_SFX": "0", "TD_SPEC_PRUNE_STATS": "0"})
+        assert _same(dense, only_sfx)
 
 
 @pytest.mark.gpu
