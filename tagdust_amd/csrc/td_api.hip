@@ -138,6 +138,7 @@ struct td_ctx {
 	uint8_t* d_ws = nullptr;      size_t cap_ws = 0;  // one workspace for all slots (decode kernels run one after the other)
 	// position pruning tables of the specialised kernel (td_spec_prune_tables), for reads up to prune_lcap bases
 	float* d_prune = nullptr;     int prune_lcap = 0, prune_stride = 0;
+	int32_t* d_tile_next = nullptr;   // tile counter of the specialised kernel's dynamic tile assignment
 };
 
 // host threads the library may use for its own copies (TD_HOST_THREADS overrides; at most 16)
@@ -268,7 +269,7 @@ extern "C" void td_ctx_destroy(td_ctx* c)
 	if (c->s_up) (void)hipStreamSynchronize(c->s_up);
 	if (c->s_down) (void)hipStreamSynchronize(c->s_down);
 	void* bufs[] = { c->d_hdr, c->d_cols, c->d_hinfo, c->d_pred_off, c->d_pred_idx, c->d_logsum, c->d_counters,
-	                 c->d_ws, c->d_art_text, c->d_art_index, c->d_prune };
+	                 c->d_ws, c->d_art_text, c->d_art_index, c->d_prune, c->d_tile_next };
 	for (void* p : bufs) if (p) (void)hipFree(p);
 	for (int k = 0; k < TD_MAX_PIPELINE; k++) slot_release(c->slots[k]);
 	if (c->s_up) (void)hipStreamDestroy(c->s_up);
@@ -862,6 +863,10 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 	// tests: every byte of the workspace the kernel reads must have been written by this launch -- garbage (NaN floats,
 	// all-ones masks) in place of whatever an earlier batch or model left there makes a read-before-write show
 	if (c->poison) HIPCHK(c, hipMemsetAsync(c->d_ws, 0xFF, (size_t)s.n_wave_slots * (size_t)s.ws_slot_bytes, c->stream));
+	if (c->spec_ready) {   // the tile counter of the dynamic tile assignment starts at zero (the first tiles go by slot number)
+		if (!c->d_tile_next) HIPCHK(c, hipMalloc((void**)&c->d_tile_next, 256));
+		HIPCHK(c, hipMemsetAsync(c->d_tile_next, 0, sizeof(int32_t), c->stream));
+	}
 	HIPCHK(c, hipEventRecord(s.ev_k0, c->stream));
 	if (c->spec_ready) {
 		TdSpecArgs sa{};
@@ -875,6 +880,7 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 		sa.art_text = ka.art_text; sa.art_index = ka.art_index; sa.art_left = ka.art_left; sa.art_n = ka.art_n; sa.art_fe = ka.art_fe;
 		sa.ws = ka.ws; sa.lay = s.slay;
 		sa.prune = c->d_prune; sa.prune_stride = c->prune_stride;
+		sa.tile_next = c->d_tile_next;
 		size_t sz = sizeof sa;
 		void* cfg[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &sa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END };
 		const int wpb = c->spec_block / TD_WAVE;

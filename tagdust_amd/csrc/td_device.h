@@ -151,4 +151,5 @@ struct TdSpecArgs {
 	TdSpecLayout lay;
 	// position pruning (td_spec_kernel.inc): four host tables of prune_stride floats each -- fb[i], bwb[m], wa[i], wb[i]
 	const float* __restrict__ prune;
+	int32_t* __restrict__ tile_next;   // tiles handed out so far beyond the first n_slots (dynamic tile assignment): zero before the launch
 };
