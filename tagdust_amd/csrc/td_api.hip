@@ -60,6 +60,10 @@ struct TdSlot {
 	TdSpecLayout slay{};
 	int32_t n_wave_slots = 0;
 	int64_t ws_slot_bytes = 0;
+	hipStream_t cs = nullptr;   // the compute stream this batch runs on (c->stream, or c->stream2 for every other pipelined batch)
+	hipStream_t aux = nullptr;  // the stream of its sort / pack kernels: cs itself, or the context's high-priority stream for them
+	hipStream_t fin = nullptr;  // ... and of its finish kernel (a stream of its own: it waits for the decode kernel, the next batch's pack must not)
+	int wsi = 0;                // ... and the workspace (0 / 1) that goes with it
 	// device
 	uint8_t* d_raw = nullptr;      size_t cap_raw = 0;
 	int64_t* d_offs = nullptr;     size_t cap_offs = 0;
@@ -80,7 +84,7 @@ struct TdSlot {
 	uint8_t* h_res = nullptr;      size_t cap_h_res = 0;
 	uint8_t* h_seq = nullptr;      size_t cap_h_seq = 0;
 	int8_t*  h_lab = nullptr;      size_t cap_h_lab = 0;
-	hipEvent_t ev_up = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr, ev_down = nullptr;
+	hipEvent_t ev_up = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr, ev_down = nullptr, ev_pack = nullptr;
 };
 
 struct td_ctx {
@@ -135,7 +139,18 @@ struct td_ctx {
 	int poison = 0;   // option "poison_workspace": fill the workspace with 0xFF bytes before every decode launch (tests)
 	int64_t ticket_counter = 0;
 	hipStream_t s_up = nullptr, s_down = nullptr;   // copy streams of the pipelined calls
-	uint8_t* d_ws = nullptr;      size_t cap_ws = 0;  // one workspace for all slots (decode kernels run one after the other)
+	uint8_t* d_ws = nullptr;      size_t cap_ws = 0;  // workspace of the decode kernels on `stream` (they run one after the other)
+	// Pipelined batches alternate between two compute streams with a workspace each: a launch ends with its slowest wave
+	// (the waves of some XCDs take ~10 % longer for the same tiles), and the next batch's workgroups move in as the first
+	// one's retire instead of waiting for the last (option "overlap_decode", TD_OVERLAP; off when HBM cannot hold both).
+	hipStream_t stream2 = nullptr;
+	// With two decode kernels queued the machine never falls idle, so the small kernels around them (sort / pack of the next
+	// batch, finish of the last one) and the download's blit kernels would wait for a whole decode kernel: they run on a
+	// high-priority stream and take the compute units the retiring workgroups free before the next decode kernel does.
+	hipStream_t s_aux = nullptr, s_fin = nullptr;
+	uint8_t* d_ws2 = nullptr;     size_t cap_ws2 = 0;
+	int32_t* d_tile_next2 = nullptr;
+	int overlap = 1, submit_parity = 0;
 	// position pruning tables of the specialised kernel (td_spec_prune_tables), for reads up to prune_lcap bases
 	float* d_prune = nullptr;     int prune_lcap = 0, prune_stride = 0;
 	int32_t* d_tile_next = nullptr;   // tile counter of the specialised kernel's dynamic tile assignment
@@ -183,6 +198,16 @@ static int fail(td_ctx* c, const char* fmt, ...)
 		hipError_t e_ = (call);                                                               \
 		if (e_ != hipSuccess) return fail((c), "%s failed: %s", #call, hipGetErrorString(e_)); \
 	} while (0)
+
+// everything queued on the compute streams has finished
+static hipError_t sync_compute(td_ctx* c)
+{
+	hipError_t e = hipStreamSynchronize(c->stream);
+	if (e == hipSuccess && c->stream2) e = hipStreamSynchronize(c->stream2);
+	if (e == hipSuccess && c->s_aux) e = hipStreamSynchronize(c->s_aux);
+	if (e == hipSuccess && c->s_fin) e = hipStreamSynchronize(c->s_fin);
+	return e;
+}
 
 template <typename T>
 static int ensure(td_ctx* c, T** p, size_t* cap, size_t bytes)
@@ -243,6 +268,7 @@ extern "C" int td_ctx_create(int device, td_ctx** out)
 	}
 	c->n_cu = prop.multiProcessorCount;
 	if (const char* e = getenv("TD_SPECIALIZE")) c->specialize = atoi(e) != 0;
+	if (const char* e = getenv("TD_OVERLAP")) c->overlap = atoi(e) != 0;
 	c->hbm_total = prop.totalGlobalMem;
 	init_logsum_host();
 	bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -266,16 +292,22 @@ extern "C" void td_ctx_destroy(td_ctx* c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+	if (c->s_aux) (void)hipStreamSynchronize(c->s_aux);
+	if (c->s_fin) (void)hipStreamSynchronize(c->s_fin);
 	if (c->s_up) (void)hipStreamSynchronize(c->s_up);
 	if (c->s_down) (void)hipStreamSynchronize(c->s_down);
 	void* bufs[] = { c->d_hdr, c->d_cols, c->d_hinfo, c->d_pred_off, c->d_pred_idx, c->d_logsum, c->d_counters,
-	                 c->d_ws, c->d_art_text, c->d_art_index, c->d_prune, c->d_tile_next };
+	                 c->d_ws, c->d_art_text, c->d_art_index, c->d_prune, c->d_tile_next, c->d_ws2, c->d_tile_next2 };
 	for (void* p : bufs) if (p) (void)hipFree(p);
 	for (int k = 0; k < TD_MAX_PIPELINE; k++) slot_release(c->slots[k]);
 	if (c->s_up) (void)hipStreamDestroy(c->s_up);
 	if (c->s_down) (void)hipStreamDestroy(c->s_down);
 	if (c->spec_mod) (void)hipModuleUnload(c->spec_mod);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
+	if (c->stream2) (void)hipStreamDestroy(c->stream2);
+	if (c->s_aux) (void)hipStreamDestroy(c->s_aux);
+	if (c->s_fin) (void)hipStreamDestroy(c->s_fin);
 	delete c;
 }
 
@@ -451,7 +483,7 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 	c->have_model = false;
 	for (int k = 0; k < TD_MAX_PIPELINE; k++) { c->slots[k].staged = false; c->slots[k].ran = false; }   // batches are staged per model
 	if (tickets_outstanding(c)) { free_dev_model(dm); return fail(c, "td_model_upload: td_submit tickets are outstanding (td_wait them first)"); }
-	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, sync_compute(c));
 	void* old[] = { c->d_hdr, c->d_cols, c->d_hinfo, c->d_pred_off, c->d_pred_idx };
 	for (void* p : old) if (p) (void)hipFree(p);
 	c->d_hdr = dm.d_hdr; c->d_cols = dm.d_cols; c->d_hinfo = dm.d_hinfo; c->d_pred_off = dm.d_pred_off; c->d_pred_idx = dm.d_pred_idx;
@@ -508,6 +540,11 @@ extern "C" int td_set_option(td_ctx* c, const char* name, int32_t value)
 		return TD_OK;
 	}
 	if (!strcmp(name, "poison_workspace")) { c->poison = value != 0; return TD_OK; }
+	if (!strcmp(name, "overlap_decode")) {
+		if (tickets_outstanding(c)) return fail(c, "td_set_option: overlap_decode cannot change while tickets are outstanding");
+		c->overlap = value != 0; c->submit_parity = 0;
+		return TD_OK;
+	}
 	if (!strcmp(name, "pipeline_depth")) {
 		if (value < 1 || value > TD_MAX_PIPELINE) return fail(c, "td_set_option: pipeline_depth must be 1..%d", TD_MAX_PIPELINE);
 		if (tickets_outstanding(c)) return fail(c, "td_set_option: pipeline_depth cannot change while tickets are outstanding");
@@ -523,6 +560,7 @@ extern "C" int td_get_option(td_ctx* c, const char* name, int32_t* value)
 	if (!strcmp(name, "specialize")) { *value = c->specialize; return TD_OK; }
 	if (!strcmp(name, "spec_lsum_clamped")) { *value = c->spec_ready && !c->spec_oob; return TD_OK; }
 	if (!strcmp(name, "pipeline_depth")) { *value = c->pipeline_depth; return TD_OK; }
+	if (!strcmp(name, "overlap_decode")) { *value = c->overlap; return TD_OK; }
 	return fail(c, "td_get_option: unknown option %s", name);
 }
 
@@ -651,6 +689,7 @@ static int slot_events(td_ctx* c, TdSlot& s)
 	HIPCHK(c, hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
 	HIPCHK(c, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
 	HIPCHK(c, hipEventCreateWithFlags(&s.ev_down, hipEventDisableTiming));
+	HIPCHK(c, hipEventCreateWithFlags(&s.ev_pack, hipEventDisableTiming));
 	return TD_OK;
 }
 
@@ -661,7 +700,7 @@ static void slot_release(TdSlot& s)
 	for (void* p : dev) if (p) (void)hipFree(p);
 	void* pinned[] = { s.h_raw, s.h_offs, s.h_res, s.h_seq, s.h_lab };
 	for (void* p : pinned) if (p) (void)hipHostFree(p);
-	hipEvent_t ev[] = { s.ev_up, s.ev_k0, s.ev_k1, s.ev_done, s.ev_down };
+	hipEvent_t ev[] = { s.ev_up, s.ev_k0, s.ev_k1, s.ev_done, s.ev_down, s.ev_pack };
 	for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
 	s = TdSlot();
 }
@@ -673,7 +712,7 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 	make_layout(s.lay, c->hdr.S, c->hdr.H, c->hdr.C, s.lmax, c->hdr.max_ncol);
 	int64_t slot_bytes = s.lay.slot_bytes;
 	if (c->spec_ready && c->spec_oob && !spec_lsum_range_ok(c, s.lmax)) {
-		HIPCHK(c, hipStreamSynchronize(c->stream));
+		HIPCHK(c, sync_compute(c));
 		if (load_spec_kernel(c, 0) != TD_OK) return TD_FAIL;   // reads this long need the clamped logsum (seconds, once)
 	}
 	if (c->spec_ready) {
@@ -684,7 +723,7 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 		slot_bytes = s.slay.slot_bytes;
 		if (s.lmax > c->prune_lcap || !c->d_prune) {
 			// bound tables of the position pruning, for reads up to lcap bases (kernels in flight read the old ones)
-			HIPCHK(c, hipStreamSynchronize(c->stream));
+			HIPCHK(c, sync_compute(c));
 			const int lcap = (s.lmax + 2 + 255) / 256 * 256, stride = lcap + 8;
 			std::vector<float> tab;
 			const int ps = td_spec_prune_segs(&c->m_desc), sf = td_spec_prune_sfx(&c->m_desc);
@@ -704,14 +743,22 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 	if (slots > s.n_tiles) slots = s.n_tiles;
 	if (slots < 1) slots = 1;
 	slots = (slots + wpb - 1) / wpb * wpb; // whole workgroups
-	if ((size_t)(slots * slot_bytes) > c->cap_ws) {
+	uint8_t*& ws = s.wsi ? c->d_ws2 : c->d_ws;
+	size_t& cap_ws = s.wsi ? c->cap_ws2 : c->cap_ws;
+	if ((size_t)(slots * slot_bytes) > cap_ws) {
 		size_t free_b = 0, total_b = 0;
 		HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-		const int64_t budget = (int64_t)((double)(free_b + c->cap_ws) * 0.85);
+		if (s.wsi == 1 && (double)(slots * slot_bytes) > 0.4 * (double)(free_b + cap_ws)) {
+			// HBM cannot hold a second workspace of this size beside the first: this and all later batches run on the first stream
+			c->overlap = 0;
+			s.wsi = 0; s.cs = c->stream;
+			return ensure_workspace(c, s);
+		}
+		const int64_t budget = (int64_t)((double)(free_b + cap_ws) * 0.85);
 		if (slots * slot_bytes > budget) slots = budget / slot_bytes / wpb * wpb;
 		if (slots < wpb) return fail(c, "td_batch_upload: workspace of %lld bytes per wave does not fit in HBM", (long long)slot_bytes);
-		if ((size_t)(slots * slot_bytes) > c->cap_ws) {
-			HIPCHK(c, hipStreamSynchronize(c->stream));
+		if ((size_t)(slots * slot_bytes) > cap_ws) {
+			HIPCHK(c, sync_compute(c));
 			const size_t need = (size_t)(slots * slot_bytes);
 			// Where the driver places a large allocation decides how fast the kernel's spill stream runs over it (up to
 			// 9 % on one box).  A large workspace is therefore chosen among a few candidates that
@@ -719,11 +766,11 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 			int n_cand = 3;
 			if (const char* e = getenv("TD_WS_CANDIDATES")) n_cand = atoi(e);
 			if (n_cand > 4) n_cand = 4;
-			if (need < ((size_t)2 << 30) || (double)need * n_cand > 0.6 * (double)(free_b + c->cap_ws)) n_cand = 1;
+			if (need < ((size_t)2 << 30) || (double)need * n_cand > 0.6 * (double)(free_b + cap_ws)) n_cand = 1;
 			if (n_cand <= 1) {
-				if (ensure(c, &c->d_ws, &c->cap_ws, need) != TD_OK) return TD_FAIL;
+				if (ensure(c, &ws, &cap_ws, need) != TD_OK) return TD_FAIL;
 			} else {
-				if (c->d_ws) { HIPCHK(c, hipFree(c->d_ws)); c->d_ws = nullptr; c->cap_ws = 0; }
+				if (ws) { HIPCHK(c, hipFree(ws)); ws = nullptr; cap_ws = 0; }
 				uint8_t* cand[4] = { nullptr, nullptr, nullptr, nullptr };
 				float ms[4] = { 0, 0, 0, 0 };
 				int n_ok = 0, best = -1;
@@ -738,7 +785,7 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 				if (best < 0) return fail(c, "td_batch_upload: workspace of %zu bytes could not be allocated", need);
 				if (getenv("TD_DEBUG_ALLOC")) fprintf(stderr, "tagdust_hip: workspace candidates: probe %.2f %.2f %.2f %.2f ms -> #%d\n", ms[0], ms[1], ms[2], ms[3], best);
 				for (int k = 0; k < n_ok; k++) if (k != best) (void)hipFree(cand[k]);
-				c->d_ws = cand[best]; c->cap_ws = need;
+				ws = cand[best]; cap_ws = need;
 			}
 		}
 	}
@@ -753,6 +800,9 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 {
 	s.staged = false; s.ran = false; s.finished = false;
 	s.n_reads = 0; s.n_tiles = 0;
+	if (!s.cs) { s.cs = c->stream; s.wsi = 0; }
+	if (!s.aux) s.aux = s.cs;
+	if (!s.fin) s.fin = s.cs;
 	if (with_workspace && !c->have_model) return fail(c, "td_batch_upload: no model uploaded");
 	if (!offs || n < 0 || (!bases && n > 0 && offs[n] > offs[0])) return fail(c, "td_batch_upload: bad arguments");
 	if (n > 0x7fffffffLL - TD_WAVE) return fail(c, "td_batch_upload: %lld reads in one batch", (long long)n);
@@ -804,12 +854,12 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 	}
 	HIPCHK(c, hipMemcpyAsync(s.d_offs, s.h_offs, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, up));
 	if (n_bases > 0) HIPCHK(c, hipMemcpyAsync(s.d_raw, src, (size_t)n_bases, hipMemcpyHostToDevice, up));
-	if (up != c->stream) {
+	if (up != s.aux) {
 		HIPCHK(c, hipEventRecord(s.ev_up, up));
-		HIPCHK(c, hipStreamWaitEvent(c->stream, s.ev_up, 0));
+		HIPCHK(c, hipStreamWaitEvent(s.aux, s.ev_up, 0));
 	}
 	if (sorted)
-		HIPCHK(c, td_stage_sort(s.d_offs, n, lmax, s.d_read_at, s.d_keys, s.d_keys + n, s.d_vals, s.d_sort_tmp, sort_tmp, c->stream));
+		HIPCHK(c, td_stage_sort(s.d_offs, n, lmax, s.d_read_at, s.d_keys, s.d_keys + n, s.d_vals, s.d_sort_tmp, sort_tmp, s.aux));
 	TdStageBatch& b = s.sb;
 	b = TdStageBatch{};
 	b.raw = s.d_raw; b.offs = s.d_offs; b.n_reads = n; b.is_ascii = is_ascii;
@@ -818,7 +868,11 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 	b.packed = s.d_packed; b.lens = s.d_lens; b.art_left = s.d_art_left;
 	b.out_soa = s.d_out; b.soa_stride = ol.soa_stride;
 	b.keep = (const uint32_t*)(s.d_out + ol.keep); b.labels = (const int8_t*)(s.d_out + ol.labels);
-	HIPCHK(c, td_stage_pack(b, c->stream));
+	HIPCHK(c, td_stage_pack(b, s.aux));
+	if (s.aux != s.cs) {   // the decode kernel's stream waits for the packed batch
+		HIPCHK(c, hipEventRecord(s.ev_pack, s.aux));
+		HIPCHK(c, hipStreamWaitEvent(s.cs, s.ev_pack, 0));
+	}
 
 	s.n_reads = n; s.n_bases = n_bases; s.n_tiles = (int32_t)n_tiles; s.is_ascii = is_ascii; s.sorted = sorted;
 	s.staged = true;
@@ -835,7 +889,7 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 	s.mode = mode; s.finished = false;
 	if (s.n_tiles == 0) { s.ran = true; s.last_ms = 0.0f; return TD_OK; }
 	if (c->spec_ready && c->match_len > 0 && !c->spec_window) {   // first batch through a window: the kernel variant that applies it
-		HIPCHK(c, hipStreamSynchronize(c->stream));
+		HIPCHK(c, sync_compute(c));
 		if (load_spec_kernel(c, c->spec_oob ? 1 : 0, 1) != TD_OK) return TD_FAIL;
 	}
 	const OutLayout ol = out_layout(s.n_tiles, s.lmax, s.nw1);
@@ -852,22 +906,23 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 	ka.out_type = (int32_t*)(soa + 5 * st); ka.out_barcode = (int32_t*)(soa + 6 * st); ka.out_finger = (int32_t*)(soa + 7 * st);
 	ka.out_keep = (uint32_t*)(s.d_out + ol.keep); ka.out_labels = (int8_t*)(s.d_out + ol.labels);
 	ka.counters = c->d_counters;
-	ka.ws = c->d_ws; ka.lay = s.lay;
+	ka.ws = s.wsi ? c->d_ws2 : c->d_ws; ka.lay = s.lay;
 	if (c->art_n > 0 && mode == TD_MODE_GET_LABEL) {
 		s.sb.art_threads = c->art_threads;
 		s.sb.art_first = c->win_first; s.sb.art_total = c->win_total;
-		HIPCHK(c, td_stage_art_left(s.sb, c->stream));
+		HIPCHK(c, td_stage_art_left(s.sb, s.cs));
 		ka.art_text = c->d_art_text; ka.art_index = c->d_art_index; ka.art_left = s.d_art_left;
 		ka.art_n = c->art_n; ka.art_fe = c->art_fe;
 	}
 	// tests: every byte of the workspace the kernel reads must have been written by this launch -- garbage (NaN floats,
 	// all-ones masks) in place of whatever an earlier batch or model left there makes a read-before-write show
-	if (c->poison) HIPCHK(c, hipMemsetAsync(c->d_ws, 0xFF, (size_t)s.n_wave_slots * (size_t)s.ws_slot_bytes, c->stream));
+	if (c->poison) HIPCHK(c, hipMemsetAsync(ka.ws, 0xFF, (size_t)s.n_wave_slots * (size_t)s.ws_slot_bytes, s.cs));
 	if (c->spec_ready) {   // the tile counter of the dynamic tile assignment starts at zero (the first tiles go by slot number)
-		if (!c->d_tile_next) HIPCHK(c, hipMalloc((void**)&c->d_tile_next, 256));
-		HIPCHK(c, hipMemsetAsync(c->d_tile_next, 0, sizeof(int32_t), c->stream));
+		int32_t*& tn = s.wsi ? c->d_tile_next2 : c->d_tile_next;
+		if (!tn) HIPCHK(c, hipMalloc((void**)&tn, 256));
+		HIPCHK(c, hipMemsetAsync(tn, 0, sizeof(int32_t), s.cs));
 	}
-	HIPCHK(c, hipEventRecord(s.ev_k0, c->stream));
+	HIPCHK(c, hipEventRecord(s.ev_k0, s.cs));
 	if (c->spec_ready) {
 		TdSpecArgs sa{};
 		sa.logsum = ka.logsum; sa.packed = ka.packed; sa.lens = ka.lens;
@@ -880,16 +935,16 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 		sa.art_text = ka.art_text; sa.art_index = ka.art_index; sa.art_left = ka.art_left; sa.art_n = ka.art_n; sa.art_fe = ka.art_fe;
 		sa.ws = ka.ws; sa.lay = s.slay;
 		sa.prune = c->d_prune; sa.prune_stride = c->prune_stride;
-		sa.tile_next = c->d_tile_next;
+		sa.tile_next = s.wsi ? c->d_tile_next2 : c->d_tile_next;
 		size_t sz = sizeof sa;
 		void* cfg[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &sa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END };
 		const int wpb = c->spec_block / TD_WAVE;
 		const unsigned blocks = (unsigned)((s.n_wave_slots + wpb - 1) / wpb);
-		HIPCHK(c, hipModuleLaunchKernel(c->spec_fn, blocks, 1, 1, (unsigned)c->spec_block, 1, 1, 0, c->stream, nullptr, cfg));
+		HIPCHK(c, hipModuleLaunchKernel(c->spec_fn, blocks, 1, 1, (unsigned)c->spec_block, 1, 1, 0, s.cs, nullptr, cfg));
 	} else {
-		HIPCHK(c, td_launch_decode(&ka, c->stream));
+		HIPCHK(c, td_launch_decode(&ka, s.cs));
 	}
-	HIPCHK(c, hipEventRecord(s.ev_k1, c->stream));
+	HIPCHK(c, hipEventRecord(s.ev_k1, s.cs));
 	s.ran = true;
 	s.last_ms = -1.0f;
 	c->last_slot = (int)(&s - c->slots);
@@ -932,9 +987,10 @@ static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* l
 	s.sb.res = res ? s.d_res : nullptr;
 	s.sb.seq_out = seq_out ? s.d_seq : nullptr;
 	s.sb.labels_out = labels ? s.d_lab : nullptr;
-	HIPCHK(c, td_stage_finish(s.sb, c->stream));
-	if (deferred) HIPCHK(c, hipEventRecord(s.ev_done, c->stream));
-	else if (slot_issue_copies(c, s, c->stream) != TD_OK) return TD_FAIL;
+	if (s.fin != s.cs) HIPCHK(c, hipStreamWaitEvent(s.fin, s.ev_k1, 0));
+	HIPCHK(c, td_stage_finish(s.sb, s.fin));
+	if (deferred) HIPCHK(c, hipEventRecord(s.ev_done, s.fin));
+	else if (slot_issue_copies(c, s, s.fin) != TD_OK) return TD_FAIL;
 	s.finished = true;
 	return TD_OK;
 }
@@ -965,6 +1021,7 @@ static int upload_common(td_ctx* c, const void* bases, int is_ascii, const int64
 	if (!c) return TD_FAIL;
 	if (tickets_outstanding(c)) return fail(c, "td_batch_upload: td_submit tickets are outstanding (td_wait them first)");
 	TdSlot& s = c->slots[0];
+	s.cs = c->stream; s.wsi = 0; s.aux = c->stream; s.fin = c->stream;
 	if (slot_stage(c, s, bases, is_ascii, offs, n, c->stream) != TD_OK) return TD_FAIL;
 	HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller may reuse its buffers
 	c->last_slot = 0;
@@ -992,7 +1049,7 @@ extern "C" int td_sync(td_ctx* c)
 {
 	if (!c) return TD_FAIL;
 	HIPCHK(c, hipSetDevice(c->device));
-	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, sync_compute(c));
 	return TD_OK;
 }
 
@@ -1013,8 +1070,12 @@ extern "C" int td_submit(td_ctx* c, const void* bases, int32_t is_ascii, const i
 	*ticket = 0;
 	HIPCHK(c, hipSetDevice(c->device));
 	if (!c->s_up) {
+		int lo = 0, hi = 0;   // (numerically lower = higher priority)
+		HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
 		HIPCHK(c, hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking));
-		HIPCHK(c, hipStreamCreateWithFlags(&c->s_down, hipStreamNonBlocking));
+		HIPCHK(c, hipStreamCreateWithPriority(&c->s_down, hipStreamNonBlocking, hi));
+		HIPCHK(c, hipStreamCreateWithPriority(&c->s_aux, hipStreamNonBlocking, hi));
+		HIPCHK(c, hipStreamCreateWithPriority(&c->s_fin, hipStreamNonBlocking, hi));
 	}
 	int k = -1;
 	for (int j = 0; j < c->pipeline_depth; j++) {   // the slot after the one used last, if free
@@ -1023,6 +1084,13 @@ extern "C" int td_submit(td_ctx* c, const void* bases, int32_t is_ascii, const i
 	}
 	if (k < 0) return fail(c, "td_submit: all %d pipeline slots hold batches that have not been waited for", c->pipeline_depth);
 	TdSlot& s = c->slots[k];
+	s.cs = c->stream; s.wsi = 0; s.aux = c->stream; s.fin = c->stream;
+	if (c->overlap && c->pipeline_depth > 1 && c->spec_ready) {   // every other batch on the second stream / workspace
+		if (!c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+		if (c->submit_parity) { s.cs = c->stream2; s.wsi = 1; }
+		c->submit_parity ^= 1;
+		s.aux = c->s_aux; s.fin = c->s_fin;
+	}
 	if (slot_stage(c, s, bases, is_ascii != 0, offs, n_reads, c->s_up) != TD_OK) return TD_FAIL;
 	if (slot_decode(c, s, mode) != TD_OK) return TD_FAIL;
 	if (slot_fetch_begin(c, s, res, labels, seq_out, true) != TD_OK) return TD_FAIL;
@@ -1057,6 +1125,7 @@ extern "C" int td_arch_scores(td_ctx* c, const td_model_desc* const* models, int
 	HIPCHK(c, hipSetDevice(c->device));
 	TdSlot& s = c->slots[0];
 	// the reads are staged (sorted by length, packed) once; no model of the context is involved
+	s.cs = c->stream; s.wsi = 0; s.aux = c->stream; s.fin = c->stream;
 	if (slot_stage(c, s, codes, 0, offs, n_reads, c->stream, false) != TD_OK) return TD_FAIL;
 	s.staged = false;                      // not a batch td_run could use: it has no workspace geometry
 	if (s.n_tiles == 0) return TD_OK;
@@ -1108,7 +1177,7 @@ extern "C" int td_arch_scores(td_ctx* c, const td_model_desc* const* models, int
 			if (chunk == 1) { cleanup(); return fail(c, "td_arch_scores: the workspace of candidate %d does not fit in HBM", k0); }
 			chunk = (chunk + 1) / 2;
 		}
-		HIPCHK(c, hipStreamSynchronize(c->stream));
+		HIPCHK(c, sync_compute(c));
 		if (ensure(c, &c->d_ws, &c->cap_ws, (size_t)ws_total) != TD_OK) { cleanup(); return TD_FAIL; }
 		for (int k = k0; k < k1; k++) {
 			const DevModel& d = dm[(size_t)k];
@@ -1193,7 +1262,9 @@ extern "C" int td_counts_reset(td_ctx* c)
 {
 	if (!c) return TD_FAIL;
 	HIPCHK(c, hipSetDevice(c->device));
+	if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));   // (kernels of pipelined batches may still be counting)
 	HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * TD_NUM_COUNTERS, c->stream));
+	if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream));
 	return TD_OK;
 }
 
@@ -1201,7 +1272,7 @@ extern "C" int td_counts_get(td_ctx* c, int64_t* counts)
 {
 	if (!c || !counts) return TD_FAIL;
 	HIPCHK(c, hipSetDevice(c->device));
-	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, sync_compute(c));
 	HIPCHK(c, hipMemcpy(counts, c->d_counters, sizeof(int64_t) * TD_NUM_COUNTERS, hipMemcpyDeviceToHost));
 	return TD_OK;
 }
