@@ -114,10 +114,12 @@ const float* td_logsum_table(void);
 int td_model_upload(td_ctx* ctx, const td_model_desc* model);
 /* Options:  "specialize" (set before td_model_upload) 1 = model-specialised kernel (default; env TD_SPECIALIZE),
  * 0 = the generic ahead-of-time kernel that reads the model from HBM;  "pipeline_depth" 1..4 (default 3) = batches
- * td_submit may hold in flight;  "poison_workspace" 1 = fill the HBM workspace with 0xFF bytes before every decode launch
+ * td_submit may hold in flight;  "overlap_decode" 1 (default; env TD_OVERLAP) = consecutive td_submit batches run their
+ * decode kernels on two streams with a workspace each, so that one batch's kernel starts while the last one's slowest waves
+ * finish (falls back to one stream when device memory cannot hold two workspaces);  "poison_workspace" 1 = fill the HBM workspace with 0xFF bytes before every decode launch
  * (tests: a kernel that reads workspace bytes it has not written in this launch then computes on NaNs). */
 int td_set_option(td_ctx* ctx, const char* name, int32_t value);
-/* Read a setting back: "specialize", "pipeline_depth", or "spec_lsum_clamped" (1 when the loaded specialised kernel uses the clamped
+/* Read a setting back: "specialize", "pipeline_depth", "overlap_decode", or "spec_lsum_clamped" (1 when the loaded specialised kernel uses the clamped
  * logsum: the clamp-free form is only selected while model parameters x read length bound every score difference). */
 int td_get_option(td_ctx* ctx, const char* name, int32_t* value);
 /* The HIP source td_model_upload would compile for this model (no GPU needed).  Returns its length; copies at
