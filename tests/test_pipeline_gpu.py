@@ -179,3 +179,53 @@ def test_new_entry_points_report_misuse():
         c.close()
     with pytest.raises(TdError, match="device"):
         TagdustMulti([0, 99])
+
+
+@pytest.mark.parametrize("overlap", [1, 0])
+def test_overlapping_launches_equal_single_stream(overlap):
+    """Consecutive pipelined batches alternate between two compute streams / workspaces ("overlap_decode"): eleven batches of
+    different sizes through a depth-4 pipeline, with a model re-upload and a counter reset in between, give the bytes the
+    synchronous path gives, and the counters add up over both streams."""
+    from tagdust_amd import RESULT_DTYPE
+    g = load_golden("c3_b6_s_r_p")
+    rng = np.random.RandomState(31 + overlap)
+    n0 = int(g["n_reads"])
+    reads = [np.asarray(g["seq"][g["offs"][i]:g["offs"][i + 1]], np.uint8) for i in range(n0)]
+    c = _ctx(g, 1, depth=4)
+    ref = _ctx(g, 1, depth=1)
+    try:
+        c.set_option("overlap_decode", overlap)
+        assert c.get_option("overlap_decode") == overlap
+        total = 0
+        for rnd in range(2):
+            if rnd == 1:
+                c.upload_model(g)               # waits for both streams, batches are staged per model
+                c.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+            c.counts_reset()
+            batches, tickets, outs = [], [], []
+            for b in range(11):
+                pick = rng.randint(0, n0, int(rng.choice([1, 63, 64, 65, 700, 3000])))
+                seq = np.concatenate([reads[i] for i in pick])
+                offs = np.concatenate([[0], np.cumsum([len(reads[i]) for i in pick])]).astype(np.int64)
+                res = np.zeros(len(pick), RESULT_DTYPE)
+                lab = np.zeros(int(offs[-1]) + len(pick), np.int8)
+                sq = np.zeros(int(offs[-1]), np.uint8)
+                batches.append((seq, offs)); outs.append((res, lab, sq))
+                tickets.append(c.submit(seq, offs, res=res, labels=lab, seq_out=sq))
+                if len(tickets) - sum(t is None for t in tickets) >= 4:
+                    k = next(i for i, t in enumerate(tickets) if t is not None)
+                    c.wait(tickets[k]); tickets[k] = None
+            for k, t in enumerate(tickets):
+                if t is not None:
+                    c.wait(t)
+            cnt = c.counts()
+            total = sum(len(o[0]) for o in outs)
+            assert int(cnt[:8].sum()) == total
+            for (seq, offs), (res, lab, sq) in zip(batches, outs):
+                ref.upload_batch(seq, offs)
+                ref.run()
+                r2, l2, s2 = ref.download()
+                assert res.tobytes() == r2.tobytes() and np.array_equal(lab, l2) and np.array_equal(sq, s2)
+    finally:
+        c.close()
+        ref.close()
