@@ -30,9 +30,11 @@ def main():
     res = {"tag": tag, "collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
            "head": open(os.path.join(REPO, ".build_head")).read().strip() if os.path.exists(os.path.join(REPO, ".build_head")) else "?",
            "kernel_source_sha16": bench.kernel_source_sha16(),
-           "profiled_command": "rocprofv3 <pass> -- python3 bench.py --steps <as the bench line> --warmup 5 --extras 0 --cpu-sample 0 --check 0 "
-                               "(the headline workload and pipeline of the bench line, without the extra workloads; averages are over "
-                               "the dispatches of the timed steps, the warm-up dispatches are left out as in bench.py)"}
+           "profiled_command": "TD_OVERLAP=0 rocprofv3 <pass> -- python3 bench.py --steps <as the bench line> --warmup 5 --extras 0 --cpu-sample 0 --check 0 "
+                               "(the headline workload and pipeline of the bench line, without the extra workloads, decode launches one after "
+                               "the other; averages are over the dispatches of the timed steps, the warm-up dispatches are left out as in "
+                               "bench.py).  kernel_trace_overlapping_launches: the same with the bench line's overlapping launches (TD_OVERLAP=1), "
+                               "where a launch's traced duration includes the time it shares the machine with its neighbour"}
     try:
         line = json.load(open(os.path.join(P, tag + "_bench_line.json")))
         res["bench_line_same_lease"] = {k: line[k] for k in ("value", "ms_per_step", "steps", "warmup")}
@@ -58,6 +60,16 @@ def main():
                 continue
             others.setdefault(r["Kernel_Name"][:60], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
         res["other_kernels_avg_ms"] = {k: {"n": len(v), "avg_ms": sum(v) / len(v)} for k, v in others.items()}
+    ko = [r for r in rows(os.path.join(out, "trace_ov", "**", "*kernel_trace.csv")) if kname in r.get("Kernel_Name", "")]
+    ko.sort(key=lambda r: int(r["Start_Timestamp"]))
+    if steps and len(ko) > steps:
+        ko = ko[-steps:]
+    if len(ko) > 1:
+        d2 = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in ko]
+        starts = [int(r["Start_Timestamp"]) for r in ko]
+        res["kernel_trace_overlapping_launches"] = {"dispatches": len(d2), "avg_ms": sum(d2) / len(d2), "min_ms": min(d2), "max_ms": max(d2),
+                                                     "avg_start_to_start_ms": (starts[-1] - starts[0]) / 1e6 / (len(starts) - 1),
+                                                     "avg_overlap_with_previous_ms": sum(max(0, int(ko[i - 1]["End_Timestamp"]) - starts[i]) for i in range(1, len(ko))) / 1e6 / (len(ko) - 1)}
     for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(P, tag + "_kernel_stats.csv"))
     pmc = {}
@@ -92,7 +104,7 @@ def main():
                           "valu_insts_per_read": p.get("SQ_INSTS_VALU", 0) / n, "lds_insts_per_read": p.get("SQ_INSTS_LDS", 0) / n,
                           "vmem_rd_insts_per_read": p.get("SQ_INSTS_VMEM_RD", 0) / n, "vmem_wr_insts_per_read": p.get("SQ_INSTS_VMEM_WR", 0) / n}
     json.dump(res, open(os.path.join(P, tag + "_td_spec_kernel_summary.json"), "w"), indent=1)
-    print(json.dumps({k: res.get(k) for k in ("bench_line_same_lease", "kernel_trace", "hbm", "derived")}, indent=1))
+    print(json.dumps({k: res.get(k) for k in ("bench_line_same_lease", "kernel_trace", "kernel_trace_overlapping_launches", "hbm", "derived")}, indent=1))
 
 
 if __name__ == "__main__":
