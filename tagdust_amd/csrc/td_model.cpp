@@ -799,12 +799,42 @@ extern "C" int td_estimate_threshold(td_ctx* ctx, const td_arch* a, const td_seq
 	td_model_tables_free(scoring);
 	if (emitted != TD_OK) return TD_FAIL;
 	int rc = TD_FAIL;
-	std::vector<td_read_result> res((size_t)cal->n_reads);
-	if (td_model_upload(ctx, &cal->scoring->desc) == TD_OK && td_batch_upload(ctx, cal->codes, cal->offs, cal->n_reads) == TD_OK &&
-	    td_run(ctx, TD_MODE_GET_PROB) == TD_OK && td_batch_download(ctx, res.data(), nullptr, nullptr) == TD_OK) {
-		std::vector<float> q((size_t)cal->n_reads);
-		for (int64_t i = 0; i < cal->n_reads; i++) q[(size_t)i] = res[(size_t)i].mapq;
-		*threshold = td_calibration_select(q.data(), cal->is_random, cal->n_reads);
+	// The simulated reads come out of the model itself: most are as long as the data, the read segment's geometric length gives
+	// a few of ten times that.  The decode workspace is laid out for a batch's longest read, so the reads are scored in three
+	// length classes (up to the 75th / 95th percentile / the rest): 30 GB of workspace instead of 260 GB for 400 000 reads of a
+	// 150-nt architecture -- which would also leave no room for the second workspace of the pipelined calls afterwards.
+	const int64_t n = cal->n_reads;
+	std::vector<float> q((size_t)n);
+	bool ok = td_model_upload(ctx, &cal->scoring->desc) == TD_OK;
+	if (ok && n > 0) {
+		std::vector<int32_t> lens((size_t)n), sorted;
+		for (int64_t i = 0; i < n; i++) lens[(size_t)i] = (int32_t)(cal->offs[i + 1] - cal->offs[i]);
+		sorted = lens;
+		std::sort(sorted.begin(), sorted.end());
+		const int32_t cut[3] = { sorted[(size_t)((n - 1) * 3 / 4)], sorted[(size_t)((n - 1) * 19 / 20)], sorted[(size_t)(n - 1)] };
+		int32_t lo = -1;
+		for (int k = 0; k < 3 && ok; k++) {
+			if (cut[k] <= lo) continue;
+			std::vector<int64_t> idx;
+			std::vector<int64_t> offs(1, 0);
+			std::vector<uint8_t> codes;
+			for (int64_t i = 0; i < n; i++) {
+				if (lens[(size_t)i] <= lo || lens[(size_t)i] > cut[k]) continue;
+				idx.push_back(i);
+				codes.insert(codes.end(), cal->codes + cal->offs[i], cal->codes + cal->offs[i + 1]);
+				offs.push_back((int64_t)codes.size());
+			}
+			lo = cut[k];
+			if (idx.empty()) continue;
+			if (codes.empty()) codes.push_back(0);
+			std::vector<td_read_result> res(idx.size());
+			ok = td_batch_upload(ctx, codes.data(), offs.data(), (int64_t)idx.size()) == TD_OK && td_run(ctx, TD_MODE_GET_PROB) == TD_OK &&
+			     td_batch_download(ctx, res.data(), nullptr, nullptr) == TD_OK;
+			for (size_t j = 0; ok && j < idx.size(); j++) q[(size_t)idx[j]] = res[j].mapq;
+		}
+	}
+	if (ok) {
+		*threshold = td_calibration_select(q.data(), cal->is_random, n);
 		rc = TD_OK;
 	}
 	td_calibration_free(cal);

@@ -46,7 +46,7 @@ def main():
         text = open(fq, "rb").read()
         st["read_file"] = time.perf_counter() - t0
         t = time.perf_counter(); pr = tdlib.ParsedReads(text, 0); st["parse"] = time.perf_counter() - t
-        c = TagdustHip(0)
+        t = time.perf_counter(); c = TagdustHip(0); st["context (HIP runtime start-up)"] = time.perf_counter() - t
         t = time.perf_counter()
         thr = tdlib.estimate_threshold(c, segs, pr.codes, pr.offs, 0.1, seed=42, n_reads=400000, rng=0)
         st["calibration (emit 400k on host, compile + score on GPU)"] = time.perf_counter() - t
@@ -59,7 +59,7 @@ def main():
         t = time.perf_counter(); c.run(); c.sync(); st["decode kernel"] = time.perf_counter() - t
         t = time.perf_counter(); res, _, seq_out = c.download(labels=False); st["D2H + unpack"] = time.perf_counter() - t
         t = time.perf_counter(); tdlib.write_demultiplexed(os.path.join(tmp, "own"), segs, pr, res, seq_out); st["write files"] = time.perf_counter() - t
-        c.close()
+        t = time.perf_counter(); c.close(); st["close (workspace free)"] = time.perf_counter() - t
         out["library"] = {"wall_s": time.perf_counter() - t0, "threshold": thr, "stages_s": {k: round(v, 3) for k, v in st.items()}}
         if exe and os.path.exists(exe):
             cores = min(len(os.sched_getaffinity(0)), 16)
