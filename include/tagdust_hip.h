@@ -212,7 +212,8 @@ void* td_counts_device_ptr(td_ctx* ctx);
 
 /* ---- measurement hooks (bench.py) ---- */
 /* Milliseconds the decode kernel of the last td_run -- or of the batch last td_wait'ed for -- took, from HIP events
- * recorded around it on the context's compute stream. */
+ * recorded around it on the stream it was launched on.  With "overlap_decode" the span of a pipelined batch's kernel includes
+ * the time it waited for compute units while the previous batch's kernel drained; td_run gives the launch's own duration. */
 int td_last_kernel_ms(td_ctx* ctx, float* ms);
 /* Number of reads resident, HBM workspace bytes, wave slots in use. */
 int td_batch_info(td_ctx* ctx, int64_t* n_reads, int64_t* workspace_bytes, int32_t* wave_slots);
