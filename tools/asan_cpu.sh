@@ -16,4 +16,4 @@ python -c "from tagdust_amd import build; build.write_embedded()"
 	-lhiprtc -ldl -o $OUT/libtagdust_hip_asan.so
 TD_LIB_PATH=$OUT/libtagdust_hip_asan.so LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
 	python -m pytest tests/test_io.py tests/test_model_builder.py tests/test_calibration.py tests/test_simreads.py tests/test_spec_source.py \
-	tests/test_shard_gloo.py -x -q -m "not gpu" -p no:cacheprovider
+	tests/test_shard_gloo.py tests/test_prune.py -x -q -m "not gpu" -p no:cacheprovider
