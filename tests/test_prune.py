@@ -195,3 +195,59 @@ def test_pruning_on_ragged_short_and_dead_reads():
     assert np.array_equal(labels, olab) and np.array_equal(seq_after, oseq)
     for k in ("read_type", "barcode", "fingerprint"):
         assert np.array_equal(res[k], ores[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_random_architectures_with_long_inserts(seed):
+    """Random segment lists as in test_parity_gpu, but with inserts of 120-220 bases: every read reaches far beyond the pruning
+    cut and far in front of the trailing segments' stop.  Specialised kernel (pruning on) == oracle, bit for bit."""
+    from oracle import pyoracle
+    from tagdust_amd import TagdustHip
+    from tagdust_amd import lib as tdlib
+    from test_parity_gpu import _random_arch
+    rng = np.random.RandomState(9000 + seed)
+    segs, parts = _random_arch(rng)
+    parts[segs.index("R:N")] = lambda: "".join("ACGT"[x] for x in rng.randint(0, 4, rng.randint(120, 221)))
+    reads = []
+    for i in range(320):
+        s_ = "".join(p() for p in parts)
+        out = []
+        for ch in s_:
+            u = rng.random_sample()
+            if u < 0.02:
+                out.append("ACGT"[rng.randint(4)])
+            elif u < 0.03:
+                continue
+            elif u < 0.04:
+                out.append(ch); out.append("ACGT"[rng.randint(4)])
+            elif u < 0.045:
+                out.append("N")
+            else:
+                out.append(ch)
+        s_ = "".join(out)
+        if rng.random_sample() < 0.1:
+            s_ = "".join("ACGT"[x] for x in rng.randint(0, 4, rng.randint(40, 240)))
+        reads.append(np.array(["ACGTN".index(ch) for ch in s_], np.uint8))
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    seq = np.concatenate(reads)
+    md, _ = tdlib.build_model(segs, seq, offs, 0.05, 0.1)
+    thr = float(rng.choice([0.0, 1.5]))
+    ores, olab, oseq = pyoracle.label_batch(pyoracle.OracleModel(md), seq, offs, thr, 16, 100, 8)
+    c = TagdustHip(0)
+    try:
+        c.set_option("poison_workspace", 1)
+        c.upload_model(md)
+        c.set_params(thr, 16, 100)
+        c.upload_batch(seq, offs)
+        c.run()
+        res, labels, seq_after = c.download()
+    finally:
+        c.close()
+    for k in ("b_score", "f_score", "r_score", "bar_prob"):
+        assert np.array_equal(res[k].view(np.uint32), ores[k].view(np.uint32)), (k, segs)
+    assert np.array_equal(labels, olab), segs
+    assert np.allclose(res["mapq"], ores["Q"], rtol=0, atol=1e-4), segs
+    for k in ("read_type", "barcode", "fingerprint"):
+        assert np.array_equal(res[k], ores[k]), (k, segs)
+    assert np.array_equal(seq_after, oseq), segs
