@@ -352,8 +352,8 @@ def measure_workload(name, n, steps, warmup, dev_index, specialize=1, depth=2, p
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=1 << 20, help="reads per step per GPU")
     ap.add_argument("--cpu-sample", type=int, default=200000, help="reads in the CPU baseline sample (0 = skip)")
     ap.add_argument("--check", type=int, default=2048, help="reads verified against the oracle before timing (0 = skip)")
