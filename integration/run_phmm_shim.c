@@ -35,12 +35,17 @@ static td_ctx* g_ctx = NULL;
 static td_multi* g_multi = NULL;   /* TAGDUST_HIP_DEVICES=0,1,...: the batches are shared out over these devices (tagdust_multi.h) */
 static uint64_t g_model_key = 0;
 
-/* one context on GPU 0, or -- with TAGDUST_HIP_DEVICES set -- one per listed device behind a td_multi (context 0 of it
- * then also serves the calls that run on one device only: architecture comparison, windowed scores) */
+/* one context per device listed in TAGDUST_HIP_DEVICES (default: "0") behind a td_multi; context 0 of it also serves the
+ * calls that run on one device only: architecture comparison, windowed scores */
 static int ensure_context(void)
 {
 	if (g_ctx) return TD_OK;
 	const char* e = getenv("TAGDUST_HIP_DEVICES");
+	/* Default: GPU 0 behind a td_multi as well -- td_multi_decode puts a batch through the pipelined calls in pieces, so that
+	 * within the one synchronous run_pHMM call the copies of one piece run beside the decode kernel of another (a 2^20-read
+	 * batch with labels: 55 ms instead of 68).  TAGDUST_HIP_SYNC=1: one context, td_batch_upload / td_run / td_batch_download. */
+	const char* sync = getenv("TAGDUST_HIP_SYNC");
+	if ((!e || !*e) && !(sync && atoi(sync) != 0)) e = "0";
 	if (e && *e) {
 		int32_t dev[64];
 		int n = 0;

@@ -200,13 +200,35 @@ extern "C" int td_multi_decode(td_multi* m, const void* bases, int32_t is_ascii,
 		int64_t lo = 0, hi = 0;
 		td_shard_bounds(n, world, k, &lo, &hi);
 		td_ctx* c = m->ctx[(size_t)k];
-		if (td_set_batch_window(c, lo, n) != TD_OK) return TD_FAIL;
-		int64_t ticket = 0;
-		// offsets keep the caller's base: read i of this range starts at offs[lo + i] in `bases` and in `seq_out`, and its
-		// labels at offs[lo + i] + (lo + i)
-		if (td_submit(c, bases, is_ascii, offs + lo, hi - lo, mode, res ? res + lo : nullptr,
-		              labels ? labels + offs[lo] + lo : nullptr, seq_out ? seq_out + offs[lo] : nullptr, &ticket) != TD_OK) return TD_FAIL;
-		return td_wait(c, ticket);
+		// A device's range goes through the pipelined calls in pieces (whole tiles of 64 reads), as many in flight as the
+		// context's pipeline is deep: the upload of one piece and the download of another run beside the decode kernel of a
+		// third, and the decode kernels overlap at their ends -- one run_pHMM call per batch stays one call for the caller.
+		// Per-read results do not depend on which reads share a tile or a launch; the artifact filter's thread ranges are those
+		// of the whole batch (td_set_batch_window per piece).
+		int pieces = (hi - lo >= (int64_t)4 << 16) ? 4 : 1;
+		if (const char* e = getenv("TD_MULTI_PIECES")) { const int v = atoi(e); if (v >= 1 && v <= 64) pieces = v; }
+		int32_t depth = 1;
+		(void)td_get_option(c, "pipeline_depth", &depth);
+		int64_t per = ((hi - lo + pieces - 1) / pieces + 63) / 64 * 64;
+		if (per < 64) per = 64;
+		std::vector<int64_t> tickets;
+		int rc = TD_OK;
+		size_t waited = 0;
+		for (int64_t a = lo; a < hi || a == lo; a += per) {
+			const int64_t b = a + per < hi ? a + per : hi;
+			if ((int)(tickets.size() - waited) >= depth) { rc = td_wait(c, tickets[waited++]); if (rc != TD_OK) break; }
+			if (td_set_batch_window(c, a, n) != TD_OK) { rc = TD_FAIL; break; }
+			int64_t ticket = 0;
+			// offsets keep the caller's base: read i of this piece starts at offs[a + i] in `bases` and in `seq_out`, and its
+			// labels at offs[a + i] + (a + i)
+			rc = td_submit(c, bases, is_ascii, offs + a, b - a, mode, res ? res + a : nullptr,
+			               labels ? labels + offs[a] + a : nullptr, seq_out ? seq_out + offs[a] : nullptr, &ticket);
+			if (rc != TD_OK) break;
+			tickets.push_back(ticket);
+			if (b >= hi) break;
+		}
+		for (; waited < tickets.size(); waited++) { const int r2 = td_wait(c, tickets[waited]); if (rc == TD_OK) rc = r2; }
+		return rc;
 	});
 	for (td_ctx* c : m->ctx) (void)td_set_batch_window(c, 0, 0);
 	if (bad >= 0) return mfail(m, "device %d: %s", m->devices[(size_t)bad], td_last_error(m->ctx[(size_t)bad]));

@@ -190,6 +190,23 @@ def test_reference_cli_over_several_contexts(tmp_path, name, extra):
 
 
 @pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("name", ["c3_b6_s_r_p", "dust_b_r"])
+def test_reference_cli_through_the_synchronous_calls(tmp_path, name):
+    """TAGDUST_HIP_SYNC=1: the shim's single-context path (td_batch_upload / td_run / td_batch_download per run_pHMM call) -- the
+    default goes through td_multi_decode's pipelined pieces."""
+    g = load_golden(name)
+    fq = str(tmp_path / "in.fq")
+    _write_fastq(g, fq)
+    args = str(g["cmdline"]).split()
+    _run("tagdust_rtest", args + [fq, "-o", "cpu"], str(tmp_path))
+    _run("tagdust_hip_rtest", args + [fq, "-o", "gpu"], str(tmp_path), env={"TAGDUST_HIP_SYNC": "1"})
+    cpu, gpu = _outputs(str(tmp_path), "cpu"), _outputs(str(tmp_path), "gpu")
+    assert cpu and set(cpu) == set(gpu)
+    for k in cpu:
+        assert cpu[k] == gpu[k], "output file *%s differs" % k
+
+
+@pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built")
 def test_config0_read_only_architecture(tmp_path):
     """BASELINE.json configs[0]: '-1 R:N' (no barcode).  The label phase of such a run is run_rna_dust() (no HMM), but
     the threshold calibration still pushes its simulated reads through run_pHMM(MODE_GET_PROB) with the one-HMM model:

@@ -73,3 +73,32 @@ def test_multi_decode_ascii_and_empty_shards():
         m.close()
     assert np.array_equal(res["read_type"], g["read_type"][:2])
     assert np.array_equal(lab, g["labels"][:offs[-1] + 2]) and np.array_equal(sq, g["seq_after"][:offs[-1]])
+
+
+@pytest.mark.parametrize("pieces,devices", [("3", [0]), ("5", [0, 0]), ("64", [0])])
+@pytest.mark.parametrize("name", ["artifacts_b_r", "c2_indel_varlen", "window_b_r"])
+def test_multi_decode_in_pipelined_pieces(name, pieces, devices, monkeypatch):
+    """td_multi_decode puts a device's range through td_submit / td_wait in pieces of whole tiles (TD_MULTI_PIECES; four for
+    large batches by default): ragged reads, an artifact filter whose thread ranges are those of the whole batch, a -start/-end
+    window -- same bytes and counters as one synchronous call on one context; more pieces than the pipeline is deep, more
+    pieces than tiles."""
+    from tagdust_amd.lib import TagdustMulti
+    monkeypatch.setenv("TD_MULTI_PIECES", pieces)
+    g = load_golden(name)
+    res1, lab1, seq1, cnt1 = _single(g, g["seq"], g["offs"])
+    m = TagdustMulti(devices)
+    try:
+        art = golden_artifacts(g)
+        if art:
+            m.set_artifacts(art[0], art[1], art[2], art[3])
+        m.upload_model(g)
+        m.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+        m.set_window(*(golden_window(g) or (-1, -1)))
+        m.counts_reset()
+        res, lab, seq = m.decode(g["seq"], g["offs"])
+        cnt = m.counts()
+    finally:
+        m.close()
+    assert res.tobytes() == res1.tobytes()
+    assert np.array_equal(lab, lab1) and np.array_equal(seq, seq1)
+    assert np.array_equal(cnt, cnt1)
