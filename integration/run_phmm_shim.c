@@ -43,7 +43,7 @@ static int ensure_context(void)
 	const char* e = getenv("TAGDUST_HIP_DEVICES");
 	/* Default: GPU 0 behind a td_multi as well -- td_multi_decode puts a batch through the pipelined calls in pieces, so that
 	 * within the one synchronous run_pHMM call the copies of one piece run beside the decode kernel of another (a 2^20-read
-	 * batch with labels: 55 ms instead of 68).  TAGDUST_HIP_SYNC=1: one context, td_batch_upload / td_run / td_batch_download. */
+	 * batch with labels: 32 ms instead of 45).  TAGDUST_HIP_SYNC=1: one context, td_batch_upload / td_run / td_batch_download. */
 	const char* sync = getenv("TAGDUST_HIP_SYNC");
 	if ((!e || !*e) && !(sync && atoi(sync) != 0)) e = "0";
 	if (e && *e) {

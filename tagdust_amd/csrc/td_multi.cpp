@@ -205,7 +205,10 @@ extern "C" int td_multi_decode(td_multi* m, const void* bases, int32_t is_ascii,
 		// third, and the decode kernels overlap at their ends -- one run_pHMM call per batch stays one call for the caller.
 		// Per-read results do not depend on which reads share a tile or a launch; the artifact filter's thread ranges are those
 		// of the whole batch (td_set_batch_window per piece).
-		int pieces = (hi - lo >= (int64_t)4 << 16) ? 4 : 1;
+		// (pieces of 2^17 reads = 2048 tiles: two of them, on the two streams, fill the 4096 wave slots of the machine)
+		int pieces = (int)((hi - lo) >> 17);
+		if (pieces > 8) pieces = 8;
+		if (pieces < 1) pieces = 1;
 		if (const char* e = getenv("TD_MULTI_PIECES")) { const int v = atoi(e); if (v >= 1 && v <= 64) pieces = v; }
 		int32_t depth = 1;
 		(void)td_get_option(c, "pipeline_depth", &depth);

@@ -78,8 +78,8 @@ def test_multi_decode_ascii_and_empty_shards():
 @pytest.mark.parametrize("pieces,devices", [("3", [0]), ("5", [0, 0]), ("64", [0])])
 @pytest.mark.parametrize("name", ["artifacts_b_r", "c2_indel_varlen", "window_b_r"])
 def test_multi_decode_in_pipelined_pieces(name, pieces, devices, monkeypatch):
-    """td_multi_decode puts a device's range through td_submit / td_wait in pieces of whole tiles (TD_MULTI_PIECES; four for
-    large batches by default): ragged reads, an artifact filter whose thread ranges are those of the whole batch, a -start/-end
+    """td_multi_decode puts a device's range through td_submit / td_wait in pieces of whole tiles (TD_MULTI_PIECES; 2^17 reads each
+    by default): ragged reads, an artifact filter whose thread ranges are those of the whole batch, a -start/-end
     window -- same bytes and counters as one synchronous call on one context; more pieces than the pipeline is deep, more
     pieces than tiles."""
     from tagdust_amd.lib import TagdustMulti
