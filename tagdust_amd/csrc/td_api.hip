@@ -727,7 +727,9 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 			const int lcap = (s.lmax + 2 + 255) / 256 * 256, stride = lcap + 8;
 			std::vector<float> tab;
 			const int ps = td_spec_prune_segs(&c->m_desc), sf = td_spec_prune_sfx(&c->m_desc);
-			if (ps > 0 || sf < c->m_desc.S) td_spec_prune_tables(&c->m_desc, ps, sf, lcap, stride, tab);
+			// (the bound recurrences cost columns x positions on the host: for reads beyond 8192 bases the tables stay zero, which
+			// the kernel reads as "nothing can be pruned" -- every position violates the zero bound -- and decodes densely)
+			if ((ps > 0 || sf < c->m_desc.S) && lcap <= 8192) td_spec_prune_tables(&c->m_desc, ps, sf, lcap, stride, tab);
 			else tab.assign((size_t)TD_PRUNE_TABLES * stride, 0.0f);
 			if (c->d_prune) { HIPCHK(c, hipFree(c->d_prune)); c->d_prune = nullptr; }
 			HIPCHK(c, hipMalloc((void**)&c->d_prune, tab.size() * sizeof(float)));

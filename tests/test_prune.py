@@ -251,3 +251,37 @@ def test_random_architectures_with_long_inserts(seed):
     for k in ("read_type", "barcode", "fingerprint"):
         assert np.array_equal(res[k], ores[k]), (k, segs)
     assert np.array_equal(seq_after, oseq), segs
+
+
+@pytest.mark.gpu
+def test_reads_beyond_the_bound_tables_decode_densely():
+    """Reads of more than 8192 bases: the host does not run the bound recurrences that far, the tables stay zero, which the
+    kernel reads as "nothing can be pruned"; a mixed batch (a few 9000-base reads among 150-base ones) equals the oracle."""
+    from oracle import pyoracle
+    from tagdust_amd import TagdustHip
+    g = load_golden("c2_b4_r")
+    rng = np.random.RandomState(17)
+    src = g["offs"]
+    reads = []
+    for i in range(96):
+        L = 9000 if i % 24 == 5 else int(rng.randint(100, 151))
+        r = rng.randint(0, 4, L).astype(np.uint8)
+        r[:4] = g["seq"][src[i]:src[i] + 4]       # a real barcode in front
+        reads.append(r)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    seq = np.concatenate(reads)
+    ores, olab, oseq = pyoracle.label_batch(pyoracle.OracleModel(g), seq, offs, float(g["threshold"]), 16, 100, 8)
+    c = TagdustHip(0)
+    try:
+        c.set_option("poison_workspace", 1)
+        c.upload_model(g)
+        c.set_params(float(g["threshold"]), 16, 100)
+        c.upload_batch(seq, offs)
+        c.run()
+        res, labels, seq_after = c.download()
+    finally:
+        c.close()
+    for k in ("b_score", "f_score", "r_score", "bar_prob"):
+        assert np.array_equal(res[k].view(np.uint32), ores[k].view(np.uint32)), k
+    assert np.array_equal(labels, olab) and np.array_equal(seq_after, oseq)
+    assert np.array_equal(res["read_type"], ores["read_type"])
