@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Position pruning on unfriendly inputs (config-3 architecture): what do the fall-backs cost when the reads are not what
+"""Position pruning on unfriendly inputs (config-3 architecture by default; usage: prune_stress.py [reads] [c3|c2|c5]): what do the fall-backs cost when the reads are not what
 the architecture expects?  For each data set: kernel ms with pruning off / on, statistics, outputs compared byte for byte."""
 import sys, os
 import numpy as np
@@ -7,11 +7,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from tagdust_amd import TagdustHip
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 18
-bench.select_workload("c3")
+wl = sys.argv[2] if len(sys.argv) > 2 else "c3"
+bench.select_workload(wl)
 model = bench.load_model()
 L = bench.READ_LEN
 rng = np.random.default_rng(3)
-good = bench.synth_batch(n, 11).reshape(n, L)
+good = np.ascontiguousarray(bench.synth_batch(n, 11)).reshape(n, L)
 
 
 def ragged(a, lens):
@@ -50,5 +51,5 @@ for name, (reads, offs) in sets.items():
     same = a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     cnt = out[1][2]
     tiles = max(int(cnt[8 + 236]), 1)
-    print("%-52s off %7.2f ms  on %7.2f ms (x%.2f)  mean cut %5.1f  mean stop %5.1f  dense tiles %d / %d  identical %s" % (
+    print(wl + " %-52s off %7.2f ms  on %7.2f ms (x%.2f)  mean cut %5.1f  mean stop %5.1f  dense tiles %d / %d  identical %s" % (
         name, out[0][0], out[1][0], out[0][0] / out[1][0], cnt[8 + 237] / tiles, cnt[8 + 227] / tiles, cnt[8 + 238], tiles, same), flush=True)
