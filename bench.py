@@ -2,14 +2,16 @@
 """bench.py -- throughput of the TagDust2 per-read HMM decoding hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`, or bare --
+    `python bench.py --gpus N` with WORLD_SIZE unset starts its own N ranks as child processes before anything touches the
+    GPU, relays rank 0's JSON line and exits non-zero if any rank does)
 
 A *step* is one run_pHMM-sized call of the hot path over one batch of synthetic reads per GPU, host to host
 (pack -> H2D -> kernels -> D2H -> extraction): the reads of a *fresh host batch* go in as base codes
 (td_submit), the device sorts and packs them, runs the fused decode kernel (backward -> forward + posteriors ->
 label DP -> Q -> extraction -> artifact filter -> DUST), rewrites the sequences and returns the per-read records and
-the rewritten sequences in input order to host buffers (td_wait).  Batches are pipelined two deep, so the copies of
-the neighbouring batches overlap the kernel -- `value` is the host-inclusive rate a caller of the C-ABI gets;
+the rewritten sequences AND the per-base labels (ri->labels, barcode_hmm.c:4503-4514) in input order to host buffers
+(td_wait).  Batches are pipelined, so the copies of the neighbouring batches overlap the kernel -- `value` is the host-inclusive rate a caller of the C-ABI gets;
 `roofline.kernel_ms` (HIP events around the decode kernel alone) and `extra.kernel_only` (the kernel on a resident
 batch, what round 1 reported) stand beside it.  The workload is the configuration BASELINE.json's metric is quoted
 on: 150 bp reads, 8-barcode architecture `-1 B:<8 of EDITTAG_6nt_ed_3> -2 S:GTA -3 R:N -4 P:AGATCGGAAGAGC`
@@ -243,30 +245,57 @@ class _DevCounters:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
 
 
-def run_pipelined(ctx, host_batches, outs, steps, depth):
-    """`steps` host-to-host batches through td_submit / td_wait, `depth` in flight; returns per-batch kernel ms."""
+def run_pipelined(ctx, host_batches, outs, steps, depth, timeline=None):
+    """`steps` host-to-host batches through td_submit / td_wait, `depth` in flight; returns per-batch kernel ms.  outs[k] =
+    (records, rewritten sequences, labels or None).  timeline: a list that receives (start_ms, stop_ms, stream) of every
+    batch's decode kernel against the context's timeline origin (HIP events on the kernel's own stream)."""
     tickets, k_ms = [], []
     trace = [] if os.environ.get("TD_BENCH_TRACE") else None
+
+    def waited():
+        k_ms.append(ctx.last_kernel_ms())
+        if timeline is not None:
+            timeline.append(ctx.last_kernel_times())
+
     for k in range(steps):
         o = outs[k % len(outs)]
         t0 = time.perf_counter()
         hb = host_batches[k % len(host_batches)]
-        tickets.append(ctx.submit(hb[0], hb[1], res=o[0], seq_out=o[1][:len(hb[0])]))
+        nb = len(hb[0])
+        tickets.append(ctx.submit(hb[0], hb[1], res=o[0], seq_out=o[1][:nb], labels=None if o[2] is None else o[2][:nb + len(hb[1]) - 1]))
         t1 = time.perf_counter()
         if len(tickets) >= depth:
             ctx.wait(tickets.pop(0))
-            k_ms.append(ctx.last_kernel_ms())
+            waited()
         if trace is not None:
             trace.append((1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t1)))
     for t in tickets:
         ctx.wait(t)
-        k_ms.append(ctx.last_kernel_ms())
+        waited()
     if trace:
         sys.stderr.write("submit/wait ms per step: " + " ".join("%.1f/%.1f" % x for x in trace) + "\n")
     return k_ms
 
 
-def measure_workload(name, n, steps, warmup, dev_index, specialize=1, depth=2, pinned=False, check=0, kernel_only_steps=0):
+def timeline_summary(tl):
+    """Start-to-start and overlap of consecutive decode launches from their HIP-event times (ms from one origin)."""
+    if len(tl) < 2:
+        return None
+    tl = sorted(tl)
+    starts = [t[0] for t in tl]
+    stops = [t[1] for t in tl]
+    n = len(tl)
+    return {"launches": n, "origin": "td_timeline_origin right before the timed region; HIP events recorded on the launch's own compute stream "
+                                      "right before / after the decode kernel (td_last_kernel_times)",
+            "start_ms": [round(x, 3) for x in starts], "stop_ms": [round(x, 3) for x in stops], "stream": [t[2] for t in tl],
+            "start_to_start_mean_ms": (starts[-1] - starts[0]) / (n - 1),
+            "stop_to_stop_mean_ms": (stops[-1] - stops[0]) / (n - 1),
+            "first_start_to_last_stop_ms": stops[-1] - starts[0],
+            "span_mean_ms": sum(b - a for a, b in zip(starts, stops)) / n,
+            "overlap_with_previous_mean_ms": sum(max(0.0, stops[i - 1] - starts[i]) for i in range(1, n)) / (n - 1)}
+
+
+def measure_workload(name, n, steps, warmup, dev_index, specialize=1, depth=2, pinned=False, check=0, kernel_only_steps=0, labels=True):
     """One workload on this rank's GPU: model upload, oracle spot-check, warm-up, then the caller times `go()`."""
     from tagdust_amd import TagdustHip, RESULT_DTYPE
     from tagdust_amd.lib import PinnedArray
@@ -295,7 +324,8 @@ def measure_workload(name, n, steps, warmup, dev_index, specialize=1, depth=2, p
         a[:] = codes
         host_batches.append((a, boffs))
     max_bases = max(len(h[0]) for h in host_batches)
-    outs = [(host_array((n,), RESULT_DTYPE), host_array((max_bases,), np.uint8)) for _ in range(depth + 1)]
+    outs = [(host_array((n,), RESULT_DTYPE), host_array((max_bases,), np.uint8),
+             host_array((max_bases + n,), np.int8) if labels else None) for _ in range(depth + 1)]
 
     if check and rank == 0:   # correctness spot-check against the oracle (outside the timed region)
         from oracle import pyoracle
@@ -320,10 +350,13 @@ def measure_workload(name, n, steps, warmup, dev_index, specialize=1, depth=2, p
     ctx.counts_reset()
     ctx.sync()
 
-    state = {"k_ms": []}
+    state = {"k_ms": [], "timeline": []}
 
-    def go():
-        state["k_ms"] = run_pipelined(ctx, host_batches, outs, steps, depth)
+    def go(n_steps=None, with_labels=True):
+        state["timeline"] = []
+        o = outs if with_labels else [(a, b, None) for a, b, _ in outs]
+        ctx.timeline_origin()
+        state["k_ms"] = run_pipelined(ctx, host_batches, o, n_steps or steps, depth, state["timeline"])
 
     def kernel_only():
         """The decode kernel alone over a resident batch (round 1's figure), outside the timed region."""
@@ -349,6 +382,74 @@ def measure_workload(name, n, steps, warmup, dev_index, specialize=1, depth=2, p
     return ctx, model, go, state, kernel_only, close, outs
 
 
+def spawn_ranks(n_ranks):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as child processes -- before this process has
+    imported torch or touched HIP, and without ever exec()ing -- with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
+    torch.distributed.run would, relay rank 0's JSON line, and exit non-zero if any rank does."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TD_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    got = []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)   # rank 0 prints its line last
+    reader.start()
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            for q in list(live):
+                c = q.poll()
+                if c is None:
+                    continue
+                live.remove(q)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 1
+                    for o in live:             # one rank failed: the others would wait for it in a barrier
+                        o.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    reader.join(timeout=10)
+    out0 = got[0] if got else b""
+    lines = [l for l in out0.decode(errors="replace").splitlines() if l.startswith("{")]
+    if rc == 0 and lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    elif rc == 0:
+        rc = 1
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
+    raise SystemExit(rc)
+
+
+def bind_rank_to_numa(dev_index, local_rank, local_world):
+    """Host side of one rank: its threads (this one, the library's copy pool, torch's) stay on the CPUs of the NUMA node next
+    to its GPU -- as far as the process may use them; when the box does not say which node that is, the ranks share the
+    allowed CPUs out evenly.  Returns a description for the bench line."""
+    from tagdust_amd import lib as tdlib
+    before = sorted(os.sched_getaffinity(0))
+    node = tdlib.bind_host_to_device(dev_index) if os.environ.get("TD_BENCH_BIND", "1") != "0" else -1
+    how = "NUMA node %d of the GPU" % node
+    if node < 0:
+        how = "unbound"
+        if local_world > 1 and os.environ.get("TD_BENCH_BIND", "1") != "0":
+            per = max(len(before) // local_world, 1)
+            mine = before[(local_rank * per) % len(before):][:per]
+            os.sched_setaffinity(0, mine)
+            how = "no NUMA information: an even share of the allowed CPUs"
+    after = sorted(os.sched_getaffinity(0))
+    return {"binding": how, "cpus": len(after), "first_cpu": after[0], "last_cpu": after[-1]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -361,29 +462,47 @@ def main():
     ap.add_argument("--specialize", type=int, default=1, help="0 = generic ahead-of-time kernel")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight (td_submit pipeline depth)")
     ap.add_argument("--pinned", type=int, default=0, help="1 = the caller's buffers are page-locked (td_host_alloc): no host copies at all")
+    ap.add_argument("--labels", type=int, default=1, help="0 = the timed region does not download the per-base labels (rounds 1-2)")
+    ap.add_argument("--sustained", type=int, default=200, help="steps of the extra sustained run (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="0 = skip the extra measurements (kernel only, pinned I/O, configs 2 and 5)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)      # does not return
     # Rank 0 prints ONE JSON line on stdout: everything else that writes to file descriptor 1 while this runs (RCCL's version
     # banner, for one) is sent to stderr, and the line goes to the real stdout at the end.
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    # host threads the library may use for its copies between pageable caller memory and pinned staging: two per GPU,
-    # so that eight ranks on one node stay far inside the host's cores
-    os.environ.setdefault("TD_HOST_THREADS", "2")
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N > 1 with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    import torch
+    if os.environ.get("TD_BENCH_DRYRUN") == "1":
+        # tests (no GPU): the launch plumbing alone -- rendezvous, barrier, one all-reduce, rank 0's line -- nothing is measured
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            real_stdout.write(json.dumps({"dryrun": True, "n_gpus": world, "rank_sum": int(t.item()),
+                                          "local_ranks_seen": os.environ.get("LOCAL_WORLD_SIZE")}) + "\n")
+            real_stdout.flush()
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
     # one rank per GPU; TD_DIST_BACKEND=gloo lets several ranks rehearse the path on a one-GPU box
     backend = os.environ.get("TD_DIST_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
+    host = bind_rank_to_numa(dev_index, local_rank, local_world)
+    # host threads of the library's copy pool (pageable caller memory <-> pinned staging): the rank's share of the CPUs, at most 8
+    os.environ.setdefault("TD_HOST_THREADS", str(max(2, min(8, host["cpus"] // 2))))
     dist = None
     use_dist = world > 1 or os.environ.get("TD_BENCH_FORCE_DIST") == "1"   # the latter: a 1-rank RCCL group on a one-GPU box
     if use_dist:
@@ -399,7 +518,7 @@ def main():
     n = args.reads
     ctx, model, go, state, kernel_only, close, outs = measure_workload(
         args.workload, n, args.steps, args.warmup, dev_index, args.specialize, args.depth, bool(args.pinned),
-        check=args.check, kernel_only_steps=5)
+        check=args.check, kernel_only_steps=5, labels=bool(args.labels))
     reduce_dev = torch.device("cuda", dev_index) if backend == "nccl" else None
     last_counts = [None]
 
@@ -425,20 +544,46 @@ def main():
         if use_dist:
             dist.barrier()
 
-    fence()
-    t0 = time.perf_counter()
-    go()
-    reduce_counts()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        if last_counts[0] is not None and int(last_counts[0][:8].sum()) != n * args.steps * world:
-            raise SystemExit("bench.py: reduced outcome counters (%d) do not add up to the reads decoded (%d)"
-                             % (int(last_counts[0][:8].sum()), n * args.steps * world))
+    def timed(n_steps, with_labels=True, reduce=True):
+        """EXACTLY n_steps steps between two fences; the MAX over ranks."""
+        fence()
+        t0 = time.perf_counter()
+        go(n_steps, with_labels)
+        if reduce:
+            reduce_counts()
+        fence()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=reduce_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    elapsed = timed(args.steps, bool(args.labels))
+    if use_dist and last_counts[0] is not None and int(last_counts[0][:8].sum()) != n * args.steps * world:
+        raise SystemExit("bench.py: reduced outcome counters (%d) do not add up to the reads decoded (%d)"
+                         % (int(last_counts[0][:8].sum()), n * args.steps * world))
     ev_ms = state["k_ms"]
+    timeline = timeline_summary(state["timeline"])
+    overlap_active = ctx.get_option("overlap_active")
+    prune_active = ctx.get_option("prune_active")
+
+    # beside the headline, on every rank (these are collective timings): the same pipeline sustained over many more steps, so
+    # that an outside clock / a GPU-busy sampler can see it, and the label-free variant rounds 1-2 reported
+    extra = {}
+    if args.extras and args.sustained > 0:
+        dt = timed(args.sustained, bool(args.labels), reduce=False)
+        tl = timeline_summary(state["timeline"])
+        extra["sustained"] = {"value": n * args.sustained * world / dt, "unit": "reads/s", "steps": args.sustained, "seconds": dt,
+                              "ms_per_step": dt / args.sustained * 1e3,
+                              "start_to_start_mean_ms": tl["start_to_start_mean_ms"] if tl else None,
+                              "overlap_with_previous_mean_ms": tl["overlap_with_previous_mean_ms"] if tl else None,
+                              "note": "the headline's pipeline (labels included) over %d steps in one timed region" % args.sustained}
+    if args.extras and args.labels:
+        st = max(args.steps, 10)
+        dt = timed(st, False, reduce=False)
+        extra["no_labels"] = {"value": n * st * world / dt, "unit": "reads/s", "steps": st, "ms_per_step": dt / st * 1e3,
+                              "note": "records + rewritten sequences only, no label download (the timed region of rounds 1-2)"}
 
     # The decode kernel's own launch duration: isolated launches over a resident batch, HIP events on the kernel's stream, in
     # this process right after the timed region.  Inside the timed region consecutive launches overlap on purpose (the next
@@ -453,7 +598,8 @@ def main():
         bpr = algorithmic_bytes_per_read(READ_LEN)
         achieved = bpr * n / (k_ms * 1e-3) / 1e9
         nreads, ws_bytes, slots = ctx.batch_info()
-        traffic, traffic_note = load_traffic(n, args.workload)
+        rec, traffic_note = load_pmc_record(n, args.workload)
+        traffic = rec.get("hbm_bytes_per_launch") if rec else None
         kname = "td_spec_kernel" if args.specialize else "td_decode_kernel"
         out = {
             "metric": "reads/s (150 bp, 8-barcode arch)", "value": value, "unit": "reads/s",
@@ -461,13 +607,18 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": _ACTIVE["name"], "read_len": READ_LEN, "reads_per_step_per_gpu": n,
-                       "timed_region": "host to host: td_submit of a fresh host batch (base codes) -> H2D -> device sort/pack -> decode "
-                                       "kernel -> device un-permute/rewrite -> D2H of records + rewritten sequences -> td_wait; "
+                       "timed_region": "host to host: td_submit of a fresh host batch (base codes; 3 distinct host batches in turn) -> H2D -> "
+                                       "device sort/pack -> decode kernel -> device un-permute/rewrite -> D2H of records + rewritten "
+                                       "sequences%s (into %d rotating sets of host buffers) -> td_wait; "
                                        "%d batches in flight, the decode kernels of consecutive batches on two streams (the next one's "
-                                       "workgroups move in as the last one's retire)" % args.depth,
+                                       "workgroups move in as the last one's retire)" % (
+                                           " + per-base labels (ri->labels, barcode_hmm.c:4503-4514)" if args.labels else "", len(outs), args.depth),
+                       "labels_downloaded": bool(args.labels),
                        "host_buffers": "page-locked (td_host_alloc)" if args.pinned else "pageable numpy arrays (library stages through pinned memory)",
-                       "host_threads": int(os.environ["TD_HOST_THREADS"]),
-                       "parallelism": "static shard of reads over %d GPU(s), counters all-reduced once per run" % world,
+                       "host_threads": int(os.environ["TD_HOST_THREADS"]), "host_binding": host,
+                       "parallelism": "static shard of reads over %d GPU(s), one process per GPU, counters all-reduced once per run (%s)" % (
+                           world, ("RCCL" if backend == "nccl" else backend) if use_dist else "single rank: no exchange"),
+                       "overlap_active": overlap_active, "prune_active": prune_active,
                        "wave_slots": slots, "workspace_bytes": ws_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -480,13 +631,13 @@ def main():
                          "traffic_gbps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
                          "traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "traffic_source": traffic_note,
-                         "note": "algorithmic bytes are tiny; the kernel's real HBM traffic is the backward-row spill "
-                                 "(traffic_gbps).  With the leading segments pruned by position (DESIGN.md section 4) that spill "
-                                 "no longer binds the kernel (~3 TB/s of the 5.5 TB/s the access pattern alone reaches, "
-                                 "tools/ubench/spill_stream.hip): what binds it now is VALU issue and the latency of the "
-                                 "table-quantised logsum chains the reference's summation order fixes"},
+                         "valu": valu_roofline(rec, n, k_ms),
+                         "note": "algorithmic bytes are tiny (SURVEY.md 8d: not HBM-bound); the kernel's real HBM traffic is the "
+                                 "backward-row spill (traffic_gbps), which no longer binds since the position pruning.  What binds is "
+                                 "the compute side: `valu` prices the kernel's VALU wave-instructions (PMC, same kernel source) against "
+                                 "the chip's issue peak"},
+            "launch_timeline": timeline,
         }
-        extra = {}
         extra["kernel_only"] = iso
     close()
     if rank == 0 and args.extras and world == 1:
@@ -496,7 +647,8 @@ def main():
                                      ("config5", "c5", n // 4, 8, False)):
             try:
                 c2, m2, go2, st2, ko2, close2, _ = measure_workload(wl, nn, st, 3, dev_index, args.specialize, args.depth, pin,
-                                                                     check=512 if wl != args.workload else 0, kernel_only_steps=3)
+                                                                     check=512 if wl != args.workload else 0, kernel_only_steps=3,
+                                                                     labels=bool(args.labels))
                 c2.sync()
                 t1 = time.perf_counter()
                 go2()
@@ -504,6 +656,7 @@ def main():
                 dt = time.perf_counter() - t1
                 extra[key] = {"value": nn * st / dt, "unit": "reads/s", "steps": st, "reads_per_step": nn,
                               "kernel_ms": float(ko2()["kernel_ms"]), "workload": WORKLOADS[wl]["name"],
+                              "overlap_active": c2.get_option("overlap_active"), "prune_active": c2.get_option("prune_active"),
                               "host_buffers": "page-locked" if pin else "pageable", "timed_region": "host to host, as the headline"}
                 close2()
             except SystemExit as e:
@@ -522,10 +675,39 @@ def main():
         dist.destroy_process_group()
 
 
-def load_traffic(n, workload):
-    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (tools/profile_lease.sh
-    collects them in the same lease as a bench run).  Only a record made for this workload, this batch size and this
-    kernel source is used; anything else gives null rather than one build's bytes over another build's time."""
+VALU_ISSUE_PEAK = 1.229e12   # wave64 VALU instructions per second: 256 CUs x 4 SIMDs x 2.4 GHz / 2 (= 157.3 TFLOP/s fp32 / 2 / 64)
+VALU_NS_FAST, VALU_NS_SLOW = 1.0, 1.75   # tools/ubench/valu_rate.hip: ns per wave64 instruction per SIMD, the two issue classes of gfx950
+
+
+def valu_roofline(rec, n, k_ms):
+    """Compute-side roofline of the decode kernel from the PMC record of the same kernel source (profiles/traffic.json):
+    VALU wave-instructions per launch against the chip's issue peak, plain and weighted with the two issue classes the
+    micro-benchmark finds (share of the slow class from the static instruction mix of the sweep loops)."""
+    if not rec or not rec.get("valu_wave_insts_per_launch"):
+        return None
+    v = float(rec["valu_wave_insts_per_launch"])
+    t = k_ms * 1e-3
+    out = {"wave_insts_per_launch": v, "wave_insts_per_read": v / n, "issue_peak_per_s": VALU_ISSUE_PEAK,
+           "achieved_per_s": v / t, "frac": v / t / VALU_ISSUE_PEAK,
+           "lds_lookups_per_read": (rec["lds_insts_per_launch"] / n) if rec.get("lds_insts_per_launch") else None,
+           "wait_any_share": rec.get("wait_any_share_of_wave_cycles"),
+           "lds_bank_conflict_share": rec.get("lds_bank_conflict_share"),
+           "source": "SQ_INSTS_VALU / SQ_INSTS_LDS / SQ_WAIT_ANY of the PMC passes in profiles/ (same kernel source hash), this run's kernel_ms"}
+    sh = rec.get("valu_slow_class_share")
+    if sh is not None:
+        ns = (1.0 - sh) * VALU_NS_FAST + sh * VALU_NS_SLOW
+        out["slow_class_share"] = sh
+        out["class_weighted_frac"] = (v / 1024.0) * ns * 1e-9 / t      # 1024 SIMDs
+        out["class_weighted_how"] = "per SIMD: instructions x (%.2f ns fast class, %.2f ns slow class; tools/ubench/valu_rate.hip) / kernel time" % (
+            VALU_NS_FAST, VALU_NS_SLOW)
+    return out
+
+
+def load_pmc_record(n, workload):
+    """The PMC record of the dominant kernel committed under profiles/ (tools/profile_lease.sh collects it in the same lease
+    as a bench run): HBM bytes per launch, VALU / LDS instruction counts, wait shares.  Only a record made for this workload,
+    this batch size and this kernel source is used; anything else gives null rather than one build's counters over another
+    build's time."""
     tpath = os.path.join(REPO, "profiles", "traffic.json")
     if not os.path.exists(tpath):
         return None, "no profiles/traffic.json"
@@ -533,12 +715,19 @@ def load_traffic(n, workload):
         tj = json.load(open(tpath))
     except Exception as e:
         return None, "profiles/traffic.json unreadable: %s" % e
-    if tj.get("reads_per_launch") != n or tj.get("workload", "c3") != workload:
-        return None, "profiles/traffic.json is for another batch size / workload"
-    if tj.get("kernel_source_sha16") != kernel_source_sha16():
-        return None, "profiles/traffic.json was collected with another kernel source (%s)" % tj.get("kernel_source_sha16")
-    return tj.get("hbm_bytes_per_launch"), "profiles/traffic.json (%s, head %s, kernel %.2f ms in that lease)" % (
-        tj.get("collected", "?"), tj.get("head", "?"), tj.get("kernel_ms_same_lease", float("nan")))
+    recs = tj.get("records") or {tj.get("workload", "c3"): tj}
+    r = recs.get(workload)
+    if not r or r.get("reads_per_launch") != n:
+        return None, "profiles/traffic.json has no record for this batch size / workload"
+    if r.get("kernel_source_sha16") != kernel_source_sha16():
+        return None, "profiles/traffic.json was collected with another kernel source (%s)" % r.get("kernel_source_sha16")
+    return r, "profiles/traffic.json (%s, head %s, kernel %.2f ms in that lease)" % (
+        r.get("collected", "?"), r.get("head", "?"), r.get("kernel_ms_same_lease", float("nan")))
+
+
+def load_traffic(n, workload):
+    rec, note = load_pmc_record(n, workload)
+    return (rec.get("hbm_bytes_per_launch") if rec else None), note
 
 
 def kernel_source_sha16():

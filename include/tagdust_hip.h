@@ -114,13 +114,19 @@ const float* td_logsum_table(void);
 int td_model_upload(td_ctx* ctx, const td_model_desc* model);
 /* Options:  "specialize" (set before td_model_upload) 1 = model-specialised kernel (default; env TD_SPECIALIZE),
  * 0 = the generic ahead-of-time kernel that reads the model from HBM;  "pipeline_depth" 1..4 (default 3) = batches
- * td_submit may hold in flight;  "overlap_decode" 1 (default; env TD_OVERLAP) = consecutive td_submit batches run their
+ * td_submit may hold in flight;  "host_threads" 1..16 (default: env TD_HOST_THREADS, else the machine's threads, at most 16) =
+ * host threads of this context for its copies between pageable caller memory and pinned staging (started once, reused);  "overlap_decode" 1 (default; env TD_OVERLAP) = consecutive td_submit batches run their
  * decode kernels on two streams with a workspace each, so that one batch's kernel starts while the last one's slowest waves
  * finish (falls back to one stream when device memory cannot hold two workspaces);  "poison_workspace" 1 = fill the HBM workspace with 0xFF bytes before every decode launch
  * (tests: a kernel that reads workspace bytes it has not written in this launch then computes on NaNs). */
 int td_set_option(td_ctx* ctx, const char* name, int32_t value);
 /* Read a setting back: "specialize", "pipeline_depth", "overlap_decode", or "spec_lsum_clamped" (1 when the loaded specialised kernel uses the clamped
- * logsum: the clamp-free form is only selected while model parameters x read length bound every score difference). */
+ * logsum: the clamp-free form is only selected while model parameters x read length bound every score difference).
+ * Which fast paths a model / batch actually got: "prune_active" (1 when the loaded specialised kernel prunes the leading /
+ * trailing segments by position and the bound tables for the last batch's read lengths are live; 0 for the generic kernel,
+ * for models without a read segment behind a bounded prefix, for reads beyond 8192 bases, before the first batch) and
+ * "overlap_active" (1 when pipelined batches really alternate between two compute streams and workspaces; 0 when the option
+ * is off, the pipeline is one deep, the generic kernel runs, or HBM could not hold the second workspace). */
 int td_get_option(td_ctx* ctx, const char* name, int32_t* value);
 /* The HIP source td_model_upload would compile for this model (no GPU needed).  Returns its length; copies at
  * most cap-1 bytes + NUL into buf when buf != NULL. */
@@ -183,13 +189,16 @@ int td_batch_download(td_ctx* ctx, td_read_result* res, int8_t* labels, uint8_t*
  * need not be 0: read i is bases[offs[i] .. offs[i+1]) and output positions count from offs[0] (seq_out + offs[i] - offs[0],
  * labels + offs[i] - offs[0] + i), so a contiguous range of a larger batch can be handed over with its own offsets.
  * At most "pipeline_depth" tickets may be outstanding (TD_FAIL beyond that).  Page-locked buffers (td_host_alloc, or
- * registered with hipHostRegister) are read and written by the DMA engines directly; any other host memory goes through
- * the library's own pinned staging with one extra host copy each way (TD_HOST_THREADS host threads, default all, <= 16). */
+ * registered with hipHostRegister) are read and written by the DMA engines directly -- td_submit then waits for the upload
+ * of `bases` before it returns, so the contract above holds for them too; any other host memory goes through
+ * the library's own pinned staging with one extra host copy each way (TD_HOST_THREADS host threads, default all, <= 16).
+ * The result buffers belong to the library until td_wait(ticket) returns. */
 int td_submit(td_ctx* ctx, const void* bases, int32_t is_ascii, const int64_t* offs, int64_t n_reads, int mode,
               td_read_result* res, int8_t* labels, uint8_t* seq_out, int64_t* ticket);
 /* Block until the batch of this ticket is complete and its results are in the buffers named at td_submit. */
 int td_wait(td_ctx* ctx, int64_t ticket);
-/* Page-locked host memory for batch inputs / outputs (NULL on failure). */
+/* Page-locked host memory for batch inputs / outputs (NULL on failure); portable: every device of the process may DMA
+ * from / to it (td_multi_decode hands ranges of one caller array to several devices). */
 void* td_host_alloc(size_t bytes);
 void  td_host_free(void* p);
 
@@ -207,6 +216,11 @@ int td_arch_scores(td_ctx* ctx, const td_model_desc* const* models, int32_t n_mo
 /* ---- counters (the reference's serial outcome counting, barcode_hmm.c:354-384, done on device) ---- */
 int td_counts_reset(td_ctx* ctx);
 int td_counts_get(td_ctx* ctx, int64_t* counts /* [TD_NUM_COUNTERS] */);
+/* The diagnostic words of the development knobs (TD_SPEC_PROFILE, TD_SPEC_PRUNE_STATS, TD_SPEC_ENDSTATS): a tail of their
+ * own behind the counters above, so that no knob can disturb what td_counts_get / the all-reduce report.  Reset with the
+ * counters.  diag[k] = historical slot 192 + k of DESIGN.md's knob table. */
+#define TD_NUM_DIAG_COUNTERS 64
+int td_diag_get(td_ctx* ctx, int64_t* diag /* [TD_NUM_DIAG_COUNTERS] */);
 /* device pointer to the int64 counters, for an in-place RCCL all-reduce over xGMI */
 void* td_counts_device_ptr(td_ctx* ctx);
 
@@ -215,6 +229,15 @@ void* td_counts_device_ptr(td_ctx* ctx);
  * recorded around it on the stream it was launched on.  With "overlap_decode" the span of a pipelined batch's kernel includes
  * the time it waited for compute units while the previous batch's kernel drained; td_run gives the launch's own duration. */
 int td_last_kernel_ms(td_ctx* ctx, float* ms);
+/* A device-side timeline of the decode launches, so that a caller can show how pipelined launches follow one another without
+ * a tracer: td_timeline_origin records the origin (an event on the context's first compute stream, waited for);
+ * td_last_kernel_times then gives, for the batch last td_run / td_wait'ed for, the milliseconds from that origin to the HIP
+ * events recorded on the batch's compute stream right before and right after its decode kernel, and which of the two
+ * compute streams / workspaces it ran on (0 / 1).  start is the moment the stream reaches the launch (the previous kernel on
+ * that stream and the batch's pack kernel are done); with "overlap_decode" the kernel's first waves may still wait for the
+ * other stream's kernel to free compute units. */
+int td_timeline_origin(td_ctx* ctx);
+int td_last_kernel_times(td_ctx* ctx, float* start_ms, float* stop_ms, int32_t* stream_index);
 /* Number of reads resident, HBM workspace bytes, wave slots in use. */
 int td_batch_info(td_ctx* ctx, int64_t* n_reads, int64_t* workspace_bytes, int32_t* wave_slots);
 

@@ -32,10 +32,18 @@ void td_shard_bounds(int64_t n_reads, int32_t world, int32_t rank, int64_t* lo, 
  * Adds to counts[TD_NUM_COUNTERS].  lens may be NULL (all reads counted). */
 void td_count_outcomes(const td_read_result* res, const int32_t* lens, int64_t n_reads, int64_t* counts);
 
+/* Bind the calling host thread to the CPUs of the NUMA node next to `device` (as far as the process may use them); returns
+ * the node, or -1 when it is unknown / none of its CPUs is available (the thread then stays where it is).  td_multi's
+ * per-device threads call it; a one-process-per-GPU launcher calls it once per rank before it allocates host buffers. */
+int32_t td_bind_host_to_device(int32_t device);
+
 /* ---- several devices driven from one process ---- */
 typedef struct td_multi td_multi;
-/* devices[n_devices] = HIP device indices (NULL: 0 .. n_devices-1).  One context and one host thread per device.
- * With n_devices > 1 distinct devices an RCCL communicator is created (librccl.so is loaded then, not before). */
+/* devices[n_devices] = HIP device indices (NULL: 0 .. n_devices-1).  One context and one host thread per device (started
+ * here, reused by every call, bound to the device's NUMA node unless TD_MULTI_BIND=0); the machine's host threads are
+ * shared out over the contexts' copy pools.  With n_devices > 1 distinct devices an RCCL communicator is created
+ * (librccl.so is loaded then, not before); TD_MULTI_FORCE_RCCL=1 creates one for a single device too, so that the
+ * collective path can be exercised on a one-GPU box. */
 int  td_multi_create(const int32_t* devices, int32_t n_devices, td_multi** out);
 void td_multi_destroy(td_multi* m);
 const char* td_multi_last_error(const td_multi* m);   /* m == NULL: the failed td_multi_create */
@@ -56,7 +64,8 @@ int  td_multi_decode(td_multi* m, const void* bases, int32_t is_ascii, const int
 /* Counters summed over the devices (all-reduced on the devices with RCCL when the communicator exists). */
 int  td_multi_counts(td_multi* m, int64_t* counts /* [TD_NUM_COUNTERS] */);
 int  td_multi_counts_reset(td_multi* m);
-/* 1 when td_multi_counts goes through ncclAllReduce, 0 when it sums on the host (one device, or a device listed twice) */
+/* 1 when td_multi_counts goes through ncclAllReduce, 0 when it sums on the host (one device without TD_MULTI_FORCE_RCCL,
+ * or a device listed twice) */
 int32_t td_multi_uses_rccl(const td_multi* m);
 
 #ifdef __cplusplus

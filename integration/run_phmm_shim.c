@@ -10,8 +10,13 @@
  * writes the results back into struct read_info exactly where do_label_thread / do_probability_estimation leave
  * them (mapq, labels, read_type, barcode, fingerprint, seq/qual rewritten in place, bar_prob = 100).
  *
- * What the GPU path does not cover (the dead training modes, -start/-end windows) is passed to
- * the reference's own CPU implementation, which the build recipe keeps available as ref_run_pHMM() (oracle/Makefile).
+ * What the GPU path does not cover is passed to the reference's own CPU implementation, which the build recipe keeps
+ * available as ref_run_pHMM() (oracle/Makefile): the dead training modes, and a -start/-end batch in which a read is
+ * shorter than matchend (the reference then reads past the end of that read -- undefined behaviour only its own code can
+ * "reproduce"; windows as such run on the GPU).  Every such hand-over is counted, and at exit the shim reports
+ *     tagdust_hip: batches gpu=<n> delegated=<m>
+ * on stderr.  TAGDUST_HIP_STRICT=1 turns a hand-over into an error (run_pHMM returns kslFAIL with a message), so that a
+ * test -- or a user -- can be sure that every result came from the GPU.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -34,6 +39,32 @@ int ref_run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** r
 static td_ctx* g_ctx = NULL;
 static td_multi* g_multi = NULL;   /* TAGDUST_HIP_DEVICES=0,1,...: the batches are shared out over these devices (tagdust_multi.h) */
 static uint64_t g_model_key = 0;
+static long g_batches_gpu = 0, g_batches_delegated = 0;
+static int g_report_registered = 0;
+
+static void report_at_exit(void)
+{
+	fprintf(stderr, "tagdust_hip: batches gpu=%ld delegated=%ld\n", g_batches_gpu, g_batches_delegated);
+}
+
+static void ensure_report(void)
+{
+	if (!g_report_registered) { g_report_registered = 1; atexit(report_at_exit); }
+}
+
+/* a batch the GPU path does not take: the reference's own code -- or, with TAGDUST_HIP_STRICT=1, an error */
+static int delegate(const char* why, struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, struct parameters* param,
+                    struct fasta* reference_fasta, int numseq, int mode)
+{
+	const char* strict = getenv("TAGDUST_HIP_STRICT");
+	ensure_report();
+	if (strict && atoi(strict) != 0) {
+		fprintf(stderr, "tagdust_hip: TAGDUST_HIP_STRICT: refusing to hand a batch of %d reads (mode %d) to the CPU path: %s\n", numseq, mode, why);
+		return kslFAIL;
+	}
+	g_batches_delegated++;
+	return ref_run_pHMM(ab, mb, ri, param, reference_fasta, numseq, mode);
+}
 
 /* one context per device listed in TAGDUST_HIP_DEVICES (default: "0") behind a td_multi; context 0 of it also serves the
  * calls that run on one device only: architecture comparison, windowed scores */
@@ -48,11 +79,24 @@ static int ensure_context(void)
 	if ((!e || !*e) && !(sync && atoi(sync) != 0)) e = "0";
 	if (e && *e) {
 		int32_t dev[64];
-		int n = 0;
-		while (*e && n < 64) {
-			dev[n++] = (int32_t)strtol(e, (char**)&e, 10);
+		int n = 0, k;
+		while (*e) {
+			char* end = NULL;
+			const long v = strtol(e, &end, 10);
+			if (end == e || v < 0 || v > 1023 || n >= 64 || (*end && *end != ',' && *end != ' ')) {
+				fprintf(stderr, "tagdust_hip: TAGDUST_HIP_DEVICES: cannot read a device index at \"%s\" (expected e.g. 0,1,2; at most 64 entries)\n", e);
+				return TD_FAIL;
+			}
+			/* (TAGDUST_HIP_ALLOW_DUPLICATE_DEVICES=1: a testing aid -- several contexts on one GPU exercise the split and the merge) */
+			for (k = 0; k < n; k++) if (dev[k] == (int32_t)v && !getenv("TAGDUST_HIP_ALLOW_DUPLICATE_DEVICES")) {
+				fprintf(stderr, "tagdust_hip: TAGDUST_HIP_DEVICES lists device %ld twice\n", v);
+				return TD_FAIL;
+			}
+			dev[n++] = (int32_t)v;
+			e = end;
 			while (*e == ',' || *e == ' ') e++;
 		}
+		if (n == 0) { fprintf(stderr, "tagdust_hip: TAGDUST_HIP_DEVICES names no device\n"); return TD_FAIL; }
 		if (td_multi_create(dev, n, &g_multi) != TD_OK) { fprintf(stderr, "tagdust_hip: %s\n", td_multi_last_error(NULL)); return TD_FAIL; }
 		g_ctx = td_multi_ctx(g_multi, 0);
 		return TD_OK;
@@ -203,16 +247,21 @@ int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, s
 	const int windowed = param->matchstart != -1 || param->matchend != -1;
 	/* not on the GPU path: the dead training modes; -start/-end windows when a read does not reach matchend -- the
 	   reference reads past the end of such a read (undefined), so its own code keeps that case */
-	if ((mode != MODE_GET_LABEL && mode != MODE_GET_PROB && mode != MODE_ARCH_COMP) || (mode == MODE_ARCH_COMP && !ab) ||
-	    (windowed && mode == MODE_ARCH_COMP))
-		return ref_run_pHMM(ab, mb, ri, param, reference_fasta, numseq, mode);
+	if (mode != MODE_GET_LABEL && mode != MODE_GET_PROB && mode != MODE_ARCH_COMP)
+		return delegate("a training mode (dead code in v2.33)", ab, mb, ri, param, reference_fasta, numseq, mode);
+	if (mode == MODE_ARCH_COMP && !ab) return delegate("architecture comparison without candidates", ab, mb, ri, param, reference_fasta, numseq, mode);
+	if (windowed && mode == MODE_ARCH_COMP) return delegate("architecture comparison inside a -start/-end window", ab, mb, ri, param, reference_fasta, numseq, mode);
 	if (windowed) {
-		if (param->matchstart < 0 || param->matchend <= param->matchstart) return ref_run_pHMM(ab, mb, ri, param, reference_fasta, numseq, mode);
-		for (i = 0; i < numseq; i++) if (ri[i]->len < param->matchend) return ref_run_pHMM(ab, mb, ri, param, reference_fasta, numseq, mode);
+		if (param->matchstart < 0 || param->matchend <= param->matchstart)
+			return delegate("a -start/-end window with start < 0 or end <= start", ab, mb, ri, param, reference_fasta, numseq, mode);
+		for (i = 0; i < numseq; i++) if (ri[i]->len < param->matchend)
+			return delegate("a read shorter than -end (the reference reads past its end)", ab, mb, ri, param, reference_fasta, numseq, mode);
 	}
 	if (numseq <= 0) return kslOK;
 
+	ensure_report();
 	if (ensure_context() != TD_OK) return kslFAIL;
+	g_batches_gpu++;
 	if (mode == MODE_ARCH_COMP) return arch_comparison(ab, ri, param, numseq);
 	if (td_set_option(g_ctx, "specialize", 1) != TD_OK) goto ERROR;
 	if (upload_model(mb, param, 1) != TD_OK) goto ERROR;

@@ -12,6 +12,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -41,6 +44,8 @@ static void init_logsum_host()
 static float p2sp(float p) { return p == 0.0f ? -INFINITY : (float)log((double)p); }
 
 #define TD_MAX_PIPELINE 4
+// the device counter block: what the ABI reports, then the diagnostic tail of the development knobs (td_diag_get)
+#define TD_COUNTER_WORDS (TD_NUM_COUNTERS + TD_NUM_DIAG_COUNTERS)
 
 // One batch on its way through the device (see "batches" below).
 struct TdSlot {
@@ -55,6 +60,7 @@ struct TdSlot {
 	td_read_result* u_res = nullptr; int8_t* u_labels = nullptr; uint8_t* u_seq = nullptr;   // the caller's output buffers
 	bool res_direct = false, lab_direct = false, seq_direct = false;                          // ... are page-locked
 	bool copies_deferred = false;   // td_wait issues the device-to-host copies (pipelined calls)
+	bool raw_direct = false;        // the upload reads the caller's page-locked buffer itself (no staging copy)
 	TdStageBatch sb{};
 	TdWsLayout lay{};
 	TdSpecLayout slay{};
@@ -87,8 +93,80 @@ struct TdSlot {
 	hipEvent_t ev_up = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr, ev_down = nullptr, ev_pack = nullptr;
 };
 
+// Host threads a context may use for its copies between pageable caller memory and pinned staging: TD_HOST_THREADS, else the
+// machine's threads, at most 16 (option "host_threads"; td_multi_create shares the machine's threads out over its devices).
+static int default_host_threads()
+{
+	int nt = (int)std::thread::hardware_concurrency();
+	if (const char* e = getenv("TD_HOST_THREADS")) nt = atoi(e);
+	if (nt > 16) nt = 16;
+	if (nt < 1) nt = 1;
+	return nt;
+}
+
+// The copy threads of one context: started once, reused by every batch (the calling thread takes a share of each copy itself).
+struct CopyPool {
+	struct Job { char* dst; const char* src; size_t bytes; };
+	std::vector<std::thread> th;
+	std::mutex mu;
+	std::condition_variable cv_job, cv_done;
+	std::deque<Job> q;
+	int pending = 0;
+	bool stop = false;
+
+	void start(int n_workers)
+	{
+		for (int k = (int)th.size(); k < n_workers; k++)
+			th.emplace_back([this] {
+				for (;;) {
+					Job j;
+					{
+						std::unique_lock<std::mutex> lk(mu);
+						cv_job.wait(lk, [this] { return stop || !q.empty(); });
+						if (q.empty()) return;   // stop
+						j = q.front(); q.pop_front();
+					}
+					memcpy(j.dst, j.src, j.bytes);
+					{
+						std::lock_guard<std::mutex> lk(mu);
+						if (--pending == 0) cv_done.notify_all();
+					}
+				}
+			});
+	}
+	// memcpy(dst, src, bytes) on nt threads (this one included)
+	void copy(void* dst, const void* src, size_t bytes, int nt)
+	{
+		const size_t chunk = (size_t)1 << 20;
+		const size_t nchunks = (bytes + chunk - 1) / chunk;
+		if ((size_t)nt > nchunks) nt = (int)nchunks;
+		if (nchunks <= 4 || nt <= 1) { memcpy(dst, src, bytes); return; }
+		start(nt - 1);
+		const size_t per = (nchunks + (size_t)nt - 1) / (size_t)nt * chunk;
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			for (size_t lo = per; lo < bytes; lo += per) {
+				q.push_back(Job{ (char*)dst + lo, (const char*)src + lo, lo + per < bytes ? per : bytes - lo });
+				pending++;
+			}
+		}
+		cv_job.notify_all();
+		memcpy(dst, src, per < bytes ? per : bytes);
+		std::unique_lock<std::mutex> lk(mu);
+		cv_done.wait(lk, [this] { return pending == 0; });
+	}
+	~CopyPool()
+	{
+		{ std::lock_guard<std::mutex> lk(mu); stop = true; }
+		cv_job.notify_all();
+		for (auto& t : th) t.join();
+	}
+};
+
 struct td_ctx {
 	int device = 0;
+	int host_threads = default_host_threads();
+	CopyPool pool;
 	hipStream_t stream = nullptr;
 	std::string err;
 	int n_cu = 0;
@@ -153,34 +231,10 @@ struct td_ctx {
 	int overlap = 1, submit_parity = 0;
 	// position pruning tables of the specialised kernel (td_spec_prune_tables), for reads up to prune_lcap bases
 	float* d_prune = nullptr;     int prune_lcap = 0, prune_stride = 0;
+	bool prune_live = false;      // ... and they are real bounds (not the all-zero tables of reads beyond 8192 bases)
 	int32_t* d_tile_next = nullptr;   // tile counter of the specialised kernel's dynamic tile assignment
+	hipEvent_t ev_origin = nullptr;   // td_timeline_origin: the common origin of td_last_kernel_times
 };
-
-// host threads the library may use for its own copies (TD_HOST_THREADS overrides; at most 16)
-static int host_threads()
-{
-	int nt = (int)std::thread::hardware_concurrency();
-	if (const char* e = getenv("TD_HOST_THREADS")) nt = atoi(e);
-	if (nt > 16) nt = 16;
-	if (nt < 1) nt = 1;
-	return nt;
-}
-
-// run fn(lo, hi) over [0, n) on the host threads
-template <typename F>
-static void parallel_ranges(int64_t n, F fn)
-{
-	int nt = host_threads();
-	if (n < 65536) nt = 1;
-	if (nt == 1) { fn((int64_t)0, n); return; }
-	std::vector<std::thread> th;
-	const int64_t per = (n + nt - 1) / nt;
-	for (int t = 0; t < nt; t++) {
-		const int64_t lo = t * per, hi = lo + per < n ? lo + per : n;
-		if (lo < hi) th.emplace_back(fn, lo, hi);
-	}
-	for (auto& t : th) t.join();
-}
 
 static int fail(td_ctx* c, const char* fmt, ...)
 {
@@ -228,7 +282,7 @@ static int ensure_pinned(td_ctx* c, T** p, size_t* cap, size_t bytes)
 	if (*p) { HIPCHK(c, hipHostFree(*p)); *p = nullptr; *cap = 0; }
 	if (bytes == 0) bytes = 256;
 	bytes += bytes / 4;   // head room: batches of a run differ a little in size
-	HIPCHK(c, hipHostMalloc((void**)p, bytes, hipHostMallocDefault));
+	HIPCHK(c, hipHostMalloc((void**)p, bytes, hipHostMallocPortable));   // (several devices of one process may DMA from it)
 	*cap = bytes;
 	return TD_OK;
 }
@@ -273,9 +327,9 @@ extern "C" int td_ctx_create(int device, td_ctx** out)
 	init_logsum_host();
 	bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
 	          hipMalloc((void**)&c->d_logsum, sizeof(float) * TD_LOGSUM_LIVE) == hipSuccess &&
-	          hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * TD_NUM_COUNTERS) == hipSuccess &&
+	          hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * TD_COUNTER_WORDS) == hipSuccess &&
 	          hipMemcpy(c->d_logsum, g_logsum, sizeof(float) * TD_LOGSUM_LIVE, hipMemcpyHostToDevice) == hipSuccess &&
-	          hipMemset(c->d_counters, 0, sizeof(unsigned long long) * TD_NUM_COUNTERS) == hipSuccess;
+	          hipMemset(c->d_counters, 0, sizeof(unsigned long long) * TD_COUNTER_WORDS) == hipSuccess;
 	if (!ok) {
 		td_ctx_destroy(c);
 		return fail(nullptr, "td_ctx_create: HIP resource allocation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -301,6 +355,7 @@ extern "C" void td_ctx_destroy(td_ctx* c)
 	                 c->d_ws, c->d_art_text, c->d_art_index, c->d_prune, c->d_tile_next, c->d_ws2, c->d_tile_next2 };
 	for (void* p : bufs) if (p) (void)hipFree(p);
 	for (int k = 0; k < TD_MAX_PIPELINE; k++) slot_release(c->slots[k]);
+	if (c->ev_origin) (void)hipEventDestroy(c->ev_origin);
 	if (c->s_up) (void)hipStreamDestroy(c->s_up);
 	if (c->s_down) (void)hipStreamDestroy(c->s_down);
 	if (c->spec_mod) (void)hipModuleUnload(c->spec_mod);
@@ -476,13 +531,14 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 {
 	if (!c || !m) return fail(c, "td_model_upload: NULL argument");
 	HIPCHK(c, hipSetDevice(c->device));
+	// a rejected upload (tickets in flight, an invalid description) leaves the context as it was
+	if (tickets_outstanding(c)) return fail(c, "td_model_upload: td_submit tickets are outstanding (td_wait them first)");
 	DevModel dm;
 	if (build_dev_model(c, m, dm) != TD_OK) return TD_FAIL;
 	const TdModelHeader h = dm.h;
 	// from here on the context holds no usable model / batch until every step below has succeeded
 	c->have_model = false;
 	for (int k = 0; k < TD_MAX_PIPELINE; k++) { c->slots[k].staged = false; c->slots[k].ran = false; }   // batches are staged per model
-	if (tickets_outstanding(c)) { free_dev_model(dm); return fail(c, "td_model_upload: td_submit tickets are outstanding (td_wait them first)"); }
 	HIPCHK(c, sync_compute(c));
 	void* old[] = { c->d_hdr, c->d_cols, c->d_hinfo, c->d_pred_off, c->d_pred_idx };
 	for (void* p : old) if (p) (void)hipFree(p);
@@ -496,7 +552,7 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 	// model-specialised kernel: compile now (seconds); a failure is an error, never a silent fallback
 	if (c->spec_mod) { HIPCHK(c, hipModuleUnload(c->spec_mod)); c->spec_mod = nullptr; }
 	c->spec_fn = nullptr; c->spec_ready = false;
-	c->prune_lcap = 0;   // the pruning tables belong to the model
+	c->prune_lcap = 0; c->prune_live = false;   // the pruning tables belong to the model
 	if (c->specialize) {
 		// keep what a later recompile needs
 		c->m_skip.assign(m->skip, m->skip + m->S);
@@ -540,6 +596,11 @@ extern "C" int td_set_option(td_ctx* c, const char* name, int32_t value)
 		return TD_OK;
 	}
 	if (!strcmp(name, "poison_workspace")) { c->poison = value != 0; return TD_OK; }
+	if (!strcmp(name, "host_threads")) {
+		if (value < 1 || value > 16) return fail(c, "td_set_option: host_threads must be 1..16");
+		c->host_threads = value;
+		return TD_OK;
+	}
 	if (!strcmp(name, "overlap_decode")) {
 		if (tickets_outstanding(c)) return fail(c, "td_set_option: overlap_decode cannot change while tickets are outstanding");
 		c->overlap = value != 0; c->submit_parity = 0;
@@ -560,7 +621,20 @@ extern "C" int td_get_option(td_ctx* c, const char* name, int32_t* value)
 	if (!strcmp(name, "specialize")) { *value = c->specialize; return TD_OK; }
 	if (!strcmp(name, "spec_lsum_clamped")) { *value = c->spec_ready && !c->spec_oob; return TD_OK; }
 	if (!strcmp(name, "pipeline_depth")) { *value = c->pipeline_depth; return TD_OK; }
+	if (!strcmp(name, "host_threads")) { *value = c->host_threads; return TD_OK; }
 	if (!strcmp(name, "overlap_decode")) { *value = c->overlap; return TD_OK; }
+	// which fast paths the model / the last batch actually got (read-only)
+	if (!strcmp(name, "prune_active")) {
+		// the loaded specialised kernel prunes by position AND the bound tables of the last batch's geometry are live
+		*value = c->spec_ready && c->prune_live && (td_spec_prune_segs(&c->m_desc) > 0 || td_spec_prune_sfx(&c->m_desc) < c->m_desc.S);
+		return TD_OK;
+	}
+	if (!strcmp(name, "overlap_active")) {
+		// pipelined batches alternate between two compute streams / workspaces (off: option, generic kernel, depth 1, or HBM
+		// could not hold the second workspace)
+		*value = c->overlap && c->pipeline_depth > 1 && c->spec_ready && c->stream2 != nullptr && c->d_ws2 != nullptr;
+		return TD_OK;
+	}
 	return fail(c, "td_get_option: unknown option %s", name);
 }
 
@@ -661,24 +735,10 @@ static bool is_pinned(const void* p)
 	return a.type == hipMemoryTypeHost;
 }
 
-// memcpy on the library's host threads (pageable caller memory <-> pinned staging)
-static void parallel_copy(void* dst, const void* src, size_t bytes)
+// memcpy on the context's host threads (pageable caller memory <-> pinned staging)
+static void parallel_copy(td_ctx* c, void* dst, const void* src, size_t bytes)
 {
-	const int64_t chunk = 1 << 20;
-	const int64_t nchunks = (int64_t)((bytes + chunk - 1) / chunk);
-	if (nchunks <= 4) { memcpy(dst, src, bytes); return; }
-	int nt = host_threads();
-	if (nt > nchunks) nt = (int)nchunks;
-	if (nt <= 1) { memcpy(dst, src, bytes); return; }
-	std::vector<std::thread> th;
-	const int64_t per = (nchunks + nt - 1) / nt;
-	for (int t = 0; t < nt; t++) {
-		const size_t lo = (size_t)(t * per * chunk);
-		size_t hi = (size_t)((t + 1) * per * chunk);
-		if (hi > bytes) hi = bytes;
-		if (lo < hi) th.emplace_back([=] { memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
-	}
-	for (auto& t : th) t.join();
+	c->pool.copy(dst, src, bytes, c->host_threads);
 }
 
 static int slot_events(td_ctx* c, TdSlot& s)
@@ -729,7 +789,8 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 			const int ps = td_spec_prune_segs(&c->m_desc), sf = td_spec_prune_sfx(&c->m_desc);
 			// (the bound recurrences cost columns x positions on the host: for reads beyond 8192 bases the tables stay zero, which
 			// the kernel reads as "nothing can be pruned" -- every position violates the zero bound -- and decodes densely)
-			if ((ps > 0 || sf < c->m_desc.S) && lcap <= 8192) td_spec_prune_tables(&c->m_desc, ps, sf, lcap, stride, tab);
+			c->prune_live = (ps > 0 || sf < c->m_desc.S) && lcap <= 8192;
+			if (c->prune_live) td_spec_prune_tables(&c->m_desc, ps, sf, lcap, stride, tab);
 			else tab.assign((size_t)TD_PRUNE_TABLES * stride, 0.0f);
 			if (c->d_prune) { HIPCHK(c, hipFree(c->d_prune)); c->d_prune = nullptr; }
 			HIPCHK(c, hipMalloc((void**)&c->d_prune, tab.size() * sizeof(float)));
@@ -849,9 +910,10 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 
 	// host -> device: page-locked caller memory goes straight to the DMA engine, anything else through pinned staging
 	const void* src = (const uint8_t*)bases + base;
-	if (n_bases > 0 && !is_pinned(src)) {
+	s.raw_direct = n_bases > 0 && is_pinned(src);
+	if (n_bases > 0 && !s.raw_direct) {
 		if (ensure_pinned(c, &s.h_raw, &s.cap_h_raw, (size_t)n_bases) != TD_OK) return TD_FAIL;
-		parallel_copy(s.h_raw, src, (size_t)n_bases);
+		parallel_copy(c, s.h_raw, src, (size_t)n_bases);
 		src = s.h_raw;
 	}
 	HIPCHK(c, hipMemcpyAsync(s.d_offs, s.h_offs, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, up));
@@ -1006,9 +1068,9 @@ static int slot_fetch_end(td_ctx* c, TdSlot& s)
 	}
 	HIPCHK(c, hipEventSynchronize(s.ev_down));
 	const int64_t n = s.n_reads;
-	if (s.u_res && !s.res_direct) parallel_copy(s.u_res, s.h_res, (size_t)n * sizeof(td_read_result));
-	if (s.u_seq && !s.seq_direct && s.n_bases) parallel_copy(s.u_seq, s.h_seq, (size_t)s.n_bases);
-	if (s.u_labels && !s.lab_direct) parallel_copy(s.u_labels, s.h_lab, (size_t)(s.n_bases + n));
+	if (s.u_res && !s.res_direct) parallel_copy(c, s.u_res, s.h_res, (size_t)n * sizeof(td_read_result));
+	if (s.u_seq && !s.seq_direct && s.n_bases) parallel_copy(c, s.u_seq, s.h_seq, (size_t)s.n_bases);
+	if (s.u_labels && !s.lab_direct) parallel_copy(c, s.u_labels, s.h_lab, (size_t)(s.n_bases + n));
 	return TD_OK;
 }
 
@@ -1096,6 +1158,9 @@ extern "C" int td_submit(td_ctx* c, const void* bases, int32_t is_ascii, const i
 	if (slot_stage(c, s, bases, is_ascii != 0, offs, n_reads, c->s_up) != TD_OK) return TD_FAIL;
 	if (slot_decode(c, s, mode) != TD_OK) return TD_FAIL;
 	if (slot_fetch_begin(c, s, res, labels, seq_out, true) != TD_OK) return TD_FAIL;
+	// "returns once the reads have left the caller's buffers": a page-locked source is read by the DMA engine itself, so wait
+	// for that copy (a few ms at PCIe rate, beside the previous batch's kernel; everything of this batch is queued already)
+	if (s.raw_direct) HIPCHK(c, hipEventSynchronize(s.ev_up));
 	s.ticket = ++c->ticket_counter;
 	c->next_slot = (k + 1) % c->pipeline_depth;
 	*ticket = s.ticket;
@@ -1224,7 +1289,7 @@ extern "C" int td_arch_scores(td_ctx* c, const td_model_desc* const* models, int
 extern "C" void* td_host_alloc(size_t bytes)
 {
 	void* p = nullptr;
-	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
 	return p;
 }
 
@@ -1247,6 +1312,32 @@ extern "C" int td_last_kernel_ms(td_ctx* c, float* ms)
 	return TD_OK;
 }
 
+extern "C" int td_timeline_origin(td_ctx* c)
+{
+	if (!c) return TD_FAIL;
+	HIPCHK(c, hipSetDevice(c->device));
+	if (!c->ev_origin) HIPCHK(c, hipEventCreate(&c->ev_origin));
+	HIPCHK(c, hipEventRecord(c->ev_origin, c->stream));
+	HIPCHK(c, hipEventSynchronize(c->ev_origin));
+	return TD_OK;
+}
+
+extern "C" int td_last_kernel_times(td_ctx* c, float* start_ms, float* stop_ms, int32_t* stream_index)
+{
+	if (!c || !start_ms || !stop_ms) return TD_FAIL;
+	TdSlot& s = c->slots[c->last_slot];
+	if (!s.ran) return fail(c, "td_last_kernel_times: nothing has run");
+	if (!c->ev_origin) return fail(c, "td_last_kernel_times: td_timeline_origin has not been called");
+	HIPCHK(c, hipSetDevice(c->device));
+	*start_ms = *stop_ms = 0.0f;
+	if (stream_index) *stream_index = s.wsi;
+	if (s.n_tiles == 0) return TD_OK;
+	HIPCHK(c, hipEventSynchronize(s.ev_k1));
+	HIPCHK(c, hipEventElapsedTime(start_ms, c->ev_origin, s.ev_k0));
+	HIPCHK(c, hipEventElapsedTime(stop_ms, c->ev_origin, s.ev_k1));
+	return TD_OK;
+}
+
 extern "C" int td_batch_info(td_ctx* c, int64_t* n_reads, int64_t* workspace_bytes, int32_t* wave_slots)
 {
 	if (!c) return TD_FAIL;
@@ -1265,7 +1356,7 @@ extern "C" int td_counts_reset(td_ctx* c)
 	if (!c) return TD_FAIL;
 	HIPCHK(c, hipSetDevice(c->device));
 	if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));   // (kernels of pipelined batches may still be counting)
-	HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * TD_NUM_COUNTERS, c->stream));
+	HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * TD_COUNTER_WORDS, c->stream));
 	if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream));
 	return TD_OK;
 }
@@ -1276,6 +1367,15 @@ extern "C" int td_counts_get(td_ctx* c, int64_t* counts)
 	HIPCHK(c, hipSetDevice(c->device));
 	HIPCHK(c, sync_compute(c));
 	HIPCHK(c, hipMemcpy(counts, c->d_counters, sizeof(int64_t) * TD_NUM_COUNTERS, hipMemcpyDeviceToHost));
+	return TD_OK;
+}
+
+extern "C" int td_diag_get(td_ctx* c, int64_t* diag)
+{
+	if (!c || !diag) return TD_FAIL;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, sync_compute(c));
+	HIPCHK(c, hipMemcpy(diag, c->d_counters + TD_NUM_COUNTERS, sizeof(int64_t) * TD_NUM_DIAG_COUNTERS, hipMemcpyDeviceToHost));
 	return TD_OK;
 }
 

@@ -7,6 +7,12 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <sched.h>
+#include <stdlib.h>
+
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -61,9 +67,99 @@ struct RcclApi {
 static RcclApi g_rccl;
 static std::string g_multi_create_error;
 
+// Bind the calling thread to the CPUs of the NUMA node the device's PCIe function hangs off (the ones the process may use
+// anyway): the staging copies of that device's batches and the pages of its pinned buffers then stay on the node next to it.
+extern "C" int32_t td_bind_host_to_device(int32_t device)
+{
+	char bus[64] = { 0 };
+	if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+	for (char* p = bus; *p; p++) if (*p >= 'A' && *p <= 'Z') *p = (char)(*p - 'A' + 'a');   // sysfs names are lower case
+	char path[160];
+	snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+	FILE* f = fopen(path, "r");
+	int node = -1;
+	if (f) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+	if (node < 0) return -1;
+	snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+	f = fopen(path, "r");
+	if (!f) return -1;
+	char list[4096] = { 0 };
+	const size_t got = fread(list, 1, sizeof list - 1, f);
+	fclose(f);
+	list[got] = 0;
+	cpu_set_t allowed, want;
+	CPU_ZERO(&want);
+	if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return -1;
+	int n_set = 0;
+	for (char* p = list; *p;) {   // "0-15,128-143"
+		char* e = nullptr;
+		const long a = strtol(p, &e, 10);
+		if (e == p) break;
+		long b = a;
+		p = e;
+		if (*p == '-') { b = strtol(p + 1, &e, 10); if (e == p + 1) break; p = e; }
+		for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (c >= 0 && CPU_ISSET((int)c, &allowed)) { CPU_SET((int)c, &want); n_set++; }
+		while (*p == ',' || *p == ' ' || *p == '\n') p++;
+	}
+	if (n_set == 0) return -1;   // none of the node's CPUs is ours: leave the thread where it is
+	if (sched_setaffinity(0, sizeof want, &want) != 0) return -1;
+	return node;
+}
+
+// One host thread per device, started with the td_multi and reused by every call (model uploads, decodes): jobs are handed
+// over one at a time and waited for.
+struct DeviceWorker {
+	std::thread th;
+	std::mutex mu;
+	std::condition_variable cv;
+	std::function<int()> job;
+	bool has_job = false, done = false, stop = false;
+	int rc = TD_OK;
+	int32_t numa_node = -1;
+
+	void start(int32_t device, bool bind)
+	{
+		th = std::thread([this, device, bind] {
+			(void)hipSetDevice(device);
+			if (bind) numa_node = td_bind_host_to_device(device);
+			for (;;) {
+				std::function<int()> j;
+				{
+					std::unique_lock<std::mutex> lk(mu);
+					cv.wait(lk, [this] { return stop || has_job; });
+					if (!has_job) return;
+					j = job; has_job = false;
+				}
+				const int r = j();
+				{ std::lock_guard<std::mutex> lk(mu); rc = r; done = true; }
+				cv.notify_all();
+			}
+		});
+	}
+	void post(std::function<int()> j)
+	{
+		{ std::lock_guard<std::mutex> lk(mu); job = std::move(j); has_job = true; done = false; }
+		cv.notify_all();
+	}
+	int wait()
+	{
+		std::unique_lock<std::mutex> lk(mu);
+		cv.wait(lk, [this] { return done; });
+		return rc;
+	}
+	~DeviceWorker()
+	{
+		if (!th.joinable()) return;
+		{ std::lock_guard<std::mutex> lk(mu); stop = true; }
+		cv.notify_all();
+		th.join();
+	}
+};
+
 struct td_multi {
 	std::vector<int32_t> devices;
 	std::vector<td_ctx*> ctx;
+	std::vector<DeviceWorker*> worker;       // one per device when there are several
 	std::vector<ncclComm_t> comm;            // empty: host sum
 	std::vector<hipStream_t> red_stream;     // per device, for the all-reduce
 	std::vector<int64_t*> d_sum;             // per device: all-reduced counters
@@ -87,11 +183,10 @@ static int for_each_device(td_multi* m, F fn)
 {
 	const int n = (int)m->ctx.size();
 	std::vector<int> rc((size_t)n, TD_OK);
-	if (n == 1) { rc[0] = fn(0); }
+	if (m->worker.empty()) { for (int k = 0; k < n; k++) rc[(size_t)k] = fn(k); }
 	else {
-		std::vector<std::thread> th;
-		for (int k = 0; k < n; k++) th.emplace_back([&, k] { rc[(size_t)k] = fn(k); });
-		for (auto& t : th) t.join();
+		for (int k = 0; k < n; k++) m->worker[(size_t)k]->post([&fn, k] { return fn(k); });
+		for (int k = 0; k < n; k++) rc[(size_t)k] = m->worker[(size_t)k]->wait();
 	}
 	for (int k = 0; k < n; k++) if (rc[(size_t)k] != TD_OK) return k;
 	return -1;
@@ -105,6 +200,8 @@ extern "C" int32_t td_multi_uses_rccl(const td_multi* m) { return m && !m->comm.
 extern "C" void td_multi_destroy(td_multi* m)
 {
 	if (!m) return;
+	for (DeviceWorker* w : m->worker) delete w;   // (joins)
+	m->worker.clear();
 	for (size_t k = 0; k < m->comm.size(); k++) if (m->comm[k]) (void)g_rccl.CommDestroy(m->comm[k]);
 	for (size_t k = 0; k < m->ctx.size(); k++) {
 		(void)hipSetDevice(m->devices[k]);
@@ -135,7 +232,23 @@ extern "C" int td_multi_create(const int32_t* devices, int32_t n_devices, td_mul
 		}
 		m->ctx.push_back(c);
 	}
-	if (n_devices > 1 && distinct) {
+	if (n_devices > 1) {
+		// the machine's host threads shared out over the devices' copy pools (TD_HOST_THREADS, when set, is per device)
+		if (!getenv("TD_HOST_THREADS")) {
+			int per = (int)std::thread::hardware_concurrency() / n_devices;
+			if (per > 16) per = 16;
+			if (per < 1) per = 1;
+			for (td_ctx* c : m->ctx) (void)td_set_option(c, "host_threads", per);
+		}
+		// worker threads bound to their device's NUMA node (TD_MULTI_BIND=0: leave them unbound)
+		const char* b = getenv("TD_MULTI_BIND");
+		const bool bind = distinct && !(b && atoi(b) == 0);
+		for (int k = 0; k < n_devices; k++) { DeviceWorker* w = new DeviceWorker(); m->worker.push_back(w); w->start(m->devices[(size_t)k], bind); }
+	}
+	// RCCL communicator: several distinct devices -- or one, when TD_MULTI_FORCE_RCCL=1 asks for the collective path on a
+	// one-GPU box (a 1-rank communicator: same calls, same library, no peer)
+	const char* force = getenv("TD_MULTI_FORCE_RCCL");
+	if (distinct && (n_devices > 1 || (force && atoi(force) != 0))) {
 		std::string why;
 		if (!g_rccl.load(why)) { td_multi_destroy(m); return mfail(nullptr, "td_multi_create: %s", why.c_str()); }
 		m->comm.assign((size_t)n_devices, nullptr);

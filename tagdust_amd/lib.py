@@ -14,17 +14,18 @@ MODE_ARCH_COMP = 5
 NUM_OUTCOME_SLOTS = 8
 NUM_BARCODE_BINS = 256
 NUM_COUNTERS = NUM_OUTCOME_SLOTS + NUM_BARCODE_BINS
+NUM_DIAG_COUNTERS = 64
 
 # every symbol include/tagdust_hip.h declares
 ABI_SYMBOLS = [
     "td_ctx_create", "td_ctx_destroy", "td_last_error", "td_logsum_table", "td_model_upload", "td_set_params",
     "td_batch_upload", "td_batch_upload_ascii", "td_run", "td_sync", "td_batch_download", "td_counts_reset",
-    "td_counts_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_batch_info", "td_set_option", "td_get_option", "td_set_artifacts", "td_spec_source", "td_spec_prune_info",
+    "td_counts_get", "td_diag_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_timeline_origin", "td_last_kernel_times", "td_batch_info", "td_set_option", "td_get_option", "td_set_artifacts", "td_spec_source", "td_spec_prune_info",
     "td_submit", "td_wait", "td_host_alloc", "td_host_free", "td_set_batch_window", "td_set_window", "td_arch_scores",
 ]
 MULTI_ABI_SYMBOLS = ["td_shard_bounds", "td_count_outcomes", "td_multi_create", "td_multi_destroy", "td_multi_last_error",
                      "td_multi_size", "td_multi_ctx", "td_multi_model_upload", "td_multi_set_params", "td_multi_set_window", "td_multi_set_artifacts",
-                     "td_multi_decode", "td_multi_counts", "td_multi_counts_reset", "td_multi_uses_rccl"]
+                     "td_multi_decode", "td_multi_counts", "td_multi_counts_reset", "td_multi_uses_rccl", "td_bind_host_to_device"]
 IO_ABI_SYMBOLS = ["td_io_last_error", "td_reads_parse", "td_reads_free", "td_writer_open", "td_writer_write", "td_writer_close",
                   "td_fasta_parse", "td_fasta_free"]
 MODEL_ABI_SYMBOLS = ["td_arch_parse", "td_arch_free", "td_sequence_stats", "td_sequence_stats_window", "td_model_build", "td_model_tables_free",
@@ -138,11 +139,19 @@ def load_library():
     lib.td_multi_counts.argtypes = [C.c_void_p, C.c_void_p]
     lib.td_multi_counts_reset.argtypes = [C.c_void_p]
     lib.td_multi_uses_rccl.argtypes = [C.c_void_p]
+    if hasattr(lib, "td_bind_host_to_device"):
+        lib.td_bind_host_to_device.argtypes = [C.c_int32]
+        lib.td_bind_host_to_device.restype = C.c_int32
     lib.td_counts_reset.argtypes = [C.c_void_p]
     lib.td_counts_get.argtypes = [C.c_void_p, C.c_void_p]
+    if hasattr(lib, "td_diag_get"):
+        lib.td_diag_get.argtypes = [C.c_void_p, C.c_void_p]
     lib.td_counts_device_ptr.argtypes = [C.c_void_p]
     lib.td_counts_device_ptr.restype = C.c_void_p
     lib.td_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    if hasattr(lib, "td_timeline_origin"):
+        lib.td_timeline_origin.argtypes = [C.c_void_p]
+        lib.td_last_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     lib.td_batch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     lib.td_arch_parse.argtypes = [C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_void_p)]
     lib.td_arch_free.argtypes = [C.c_void_p]
@@ -550,10 +559,25 @@ class TagdustHip:
         self._chk(self.lib.td_counts_get(self.h, c.ctypes.data))
         return c
 
+    def diag(self):
+        """td_diag_get: the 64 diagnostic words of the development knobs (word k = historical slot 192 + k)."""
+        d = np.zeros(NUM_DIAG_COUNTERS, np.int64)
+        self._chk(self.lib.td_diag_get(self.h, d.ctypes.data))
+        return d
+
     def last_kernel_ms(self):
         ms = C.c_float()
         self._chk(self.lib.td_last_kernel_ms(self.h, C.byref(ms)))
         return float(ms.value)
+
+    def timeline_origin(self):
+        self._chk(self.lib.td_timeline_origin(self.h))
+
+    def last_kernel_times(self):
+        """(start_ms, stop_ms, stream index) of the last batch's decode kernel, from the origin set by timeline_origin()."""
+        a, b, k = C.c_float(), C.c_float(), C.c_int32()
+        self._chk(self.lib.td_last_kernel_times(self.h, C.byref(a), C.byref(b), C.byref(k)))
+        return float(a.value), float(b.value), int(k.value)
 
     def batch_info(self):
         n, w, s = C.c_int64(), C.c_int64(), C.c_int32()
@@ -585,6 +609,11 @@ class PinnedArray:
             self.free()
         except Exception:
             pass
+
+
+def bind_host_to_device(device):
+    """td_bind_host_to_device: pin the calling thread to the CPUs of the NUMA node next to `device`; returns the node or -1."""
+    return int(load_library().td_bind_host_to_device(int(device)))
 
 
 def shard_bounds(n_reads, world, rank):

@@ -5,6 +5,7 @@ calibration with run_pHMM() bound to libtagdust_hip.so through integration/run_p
 dev/bar_read_test.sh scenario 1.  Both binaries are built by `make -C oracle ref` in the build container."""
 import glob
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -34,12 +35,22 @@ def _write_fastq(g, path):
             fh.write(b"@" + names[i] + b"\n" + s + b"\n+\n" + q + b"\n")
 
 
-def _run(binary, args, cwd, env=None):
+def _run(binary, args, cwd, env=None, strict=True):
+    """Run a binary of oracle/_ref.  The GPU-bound one runs with TAGDUST_HIP_STRICT=1 (the shim fails instead of handing a batch
+    to the reference's CPU code) and must report at exit that it decoded at least one batch on the GPU and delegated none:
+    a byte-identical file then really comes from the HIP path."""
     e = dict(os.environ)
+    if binary == "tagdust_hip_rtest" and strict:
+        e["TAGDUST_HIP_STRICT"] = "1"
     e.update(env or {})
     p = subprocess.run([os.path.join(RBIN, binary)] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=e)
-    assert p.returncode == 0, p.stdout.decode(errors="replace")[-2000:]
-    return p.stdout.decode(errors="replace")
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0, out[-2000:]
+    if binary == "tagdust_hip_rtest" and strict:
+        assert "TAGDUST_HIP_STRICT: refusing" not in out, out[-2000:]
+        rep = re.findall(r"tagdust_hip: batches gpu=(\d+) delegated=(\d+)", out)
+        assert rep and int(rep[-1][0]) > 0 and int(rep[-1][1]) == 0, out[-2000:]
+    return out
 
 
 def _outputs(d, prefix):
@@ -182,7 +193,7 @@ def test_reference_cli_over_several_contexts(tmp_path, name, extra):
         open(fa, "wb").write(bytes(g["art_fasta_text"]))
         args[args.index("-ref") + 1] = fa
     _run("tagdust_rtest", args + [fq, "-o", "cpu"], str(tmp_path))
-    log = _run("tagdust_hip_rtest", args + [fq, "-o", "gpu"], str(tmp_path), env={"TAGDUST_HIP_DEVICES": "0,0,0"})
+    log = _run("tagdust_hip_rtest", args + [fq, "-o", "gpu"], str(tmp_path), env={"TAGDUST_HIP_DEVICES": "0,0,0", "TAGDUST_HIP_ALLOW_DUPLICATE_DEVICES": "1"})
     cpu, gpu = _outputs(str(tmp_path), "cpu"), _outputs(str(tmp_path), "gpu")
     assert cpu and set(cpu) == set(gpu), (sorted(cpu), sorted(gpu), log[-1500:])
     for k in cpu:
@@ -257,3 +268,38 @@ def test_casava_three_file_run_with_arch_file(tmp_path):
     for k in cpu:
         assert cpu[k] == gpu[k], "output file *%s differs" % k
     assert any("_READ1" in k for k in cpu) and any("_READ2" in k for k in cpu)
+
+
+@pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built")
+def test_short_read_in_a_window_is_delegated_or_refused(tmp_path):
+    """The one hand-over left in the shim: a -start/-end batch with a read shorter than -end (the reference reads past the end of
+    such a read; only its own code can do "the same").  Without TAGDUST_HIP_STRICT the batch goes to ref_run_pHMM and the exit
+    report says so; with it the shim refuses, loudly, and decodes nothing."""
+    g = load_golden("window_b_r")
+    fq = str(tmp_path / "in.fq")
+    _write_fastq(g, fq)
+    lines = open(fq, "rb").read().split(b"\n")
+    lines[1], lines[3] = lines[1][:40], lines[3][:40]          # the first read now ends before -end 61
+    open(fq, "wb").write(b"\n".join(lines))
+    args = str(g["cmdline"]).split()
+    out = _run("tagdust_hip_rtest", args + [fq, "-o", "loose"], str(tmp_path), strict=False)
+    rep = re.findall(r"tagdust_hip: batches gpu=(\d+) delegated=(\d+)", out)
+    assert rep and rep[-1] == ("0", "1"), out[-1500:]
+    out = _run("tagdust_hip_rtest", args + [fq, "-o", "strict"], str(tmp_path), env={"TAGDUST_HIP_STRICT": "1"}, strict=False)
+    assert "TAGDUST_HIP_STRICT: refusing" in out and "shorter than -end" in out
+    rep = re.findall(r"tagdust_hip: batches gpu=(\d+) delegated=(\d+)", out)
+    assert rep and rep[-1] == ("0", "0"), out[-1500:]
+
+
+@pytest.mark.skipif(not _have(), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("devs", ["gpu0", "0;1", "0,0", "-1", ""], ids=["text", "semicolon", "twice", "negative", "empty-uses-default"])
+def test_device_list_parse_errors_are_reported(tmp_path, devs):
+    """TAGDUST_HIP_DEVICES must be a list of distinct non-negative indices; anything else ends the run with a message instead
+    of 64 contexts on device 0."""
+    g = load_golden("c2_b4_r")
+    fq = str(tmp_path / "in.fq")
+    _write_fastq(g, fq)
+    args = str(g["cmdline"]).split()
+    out = _run("tagdust_hip_rtest", args + [fq, "-o", "x"], str(tmp_path), env={"TAGDUST_HIP_DEVICES": devs}, strict=(devs == ""))
+    if devs:
+        assert "TAGDUST_HIP_DEVICES" in out and not re.findall(r"batches gpu=[1-9]", out), out[-1500:]

@@ -1,7 +1,8 @@
 """Several devices driven from one process (include/tagdust_multi.h).  A GPU box of this pool has one MI355X, so what can
-run here is N = 1 (must equal the single-context path bit for bit) and two contexts on the same device (the split, the
-per-device windows of the artifact filter, the input-order merge and the counter sum; the RCCL all-reduce itself needs
-distinct devices and is exercised by the driver's multi-GPU runs only)."""
+run here is N = 1 (must equal the single-context path bit for bit), two contexts on the same device (the split, the
+per-device windows of the artifact filter, the input-order merge and the counter sum) and the library's RCCL path on a
+1-rank communicator (TD_MULTI_FORCE_RCCL=1: librccl.so loaded, ncclCommInitAll, ncclAllReduce on the device counters).
+test_multi_distinct_devices runs wherever two GPUs are visible."""
 import numpy as np
 import pytest
 
@@ -102,3 +103,77 @@ def test_multi_decode_in_pipelined_pieces(name, pieces, devices, monkeypatch):
     assert res.tobytes() == res1.tobytes()
     assert np.array_equal(lab, lab1) and np.array_equal(seq, seq1)
     assert np.array_equal(cnt, cnt1)
+
+
+def test_counts_through_rccl_on_a_one_rank_communicator(monkeypatch):
+    """The collective path of the library itself on the one-GPU box: td_multi_create builds an RCCL communicator for the single
+    device, td_multi_counts sums the device counters with ncclAllReduce into the second buffer and reads that back; the
+    result equals td_counts_get of the context and serial counting, twice in a row (the running counters stay untouched)."""
+    from tagdust_amd import lib as tdlib
+    from tagdust_amd.lib import TagdustMulti
+    import ctypes as C
+    monkeypatch.setenv("TD_MULTI_FORCE_RCCL", "1")
+    g = load_golden("c3_b6_s_r_p")
+    m = TagdustMulti([0])
+    try:
+        assert m.uses_rccl()
+        m.upload_model(g)
+        m.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+        m.counts_reset()
+        res, lab, seq = m.decode(g["seq"], g["offs"])
+        cnt = m.counts()
+        direct = np.zeros(tdlib.NUM_COUNTERS, np.int64)
+        assert m.lib.td_counts_get(C.c_void_p(m.lib.td_multi_ctx(m.h, 0)), direct.ctypes.data) == 0
+        assert np.array_equal(cnt, direct) and np.array_equal(cnt, tdlib.count_outcomes(res, g["lens"]))
+        assert int(cnt[:8].sum()) == int((g["lens"] > 0).sum())
+        res2, _, _ = m.decode(g["seq"], g["offs"])
+        assert res2.tobytes() == res.tobytes()
+        assert np.array_equal(m.counts(), 2 * cnt)
+    finally:
+        m.close()
+    assert np.array_equal(res["read_type"], g["read_type"]) and np.array_equal(lab, g["labels"])
+
+
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()     # (does not initialise the GPU on this image)
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="needs two visible GPUs (a GPU box of this pool has one)")
+@pytest.mark.parametrize("name", ["c3_b6_s_r_p", "artifacts_b_r", "c2_indel_varlen"])
+def test_multi_distinct_devices(name):
+    """Two physical devices: RCCL communicator over both, one worker thread per device, DMA from one caller array by both --
+    results and counters bit-equal to the single context."""
+    from tagdust_amd.lib import TagdustMulti
+    g = load_golden(name)
+    res1, lab1, seq1, cnt1 = _single(g, g["seq"], g["offs"])
+    m = TagdustMulti([0, 1])
+    try:
+        assert m.uses_rccl()
+        art = golden_artifacts(g)
+        if art:
+            m.set_artifacts(art[0], art[1], art[2], art[3])
+        m.upload_model(g)
+        m.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+        m.counts_reset()
+        res, lab, seq = m.decode(g["seq"], g["offs"])
+        cnt = m.counts()
+    finally:
+        m.close()
+    assert res.tobytes() == res1.tobytes()
+    assert np.array_equal(lab, lab1) and np.array_equal(seq, seq1)
+    assert np.array_equal(cnt, cnt1)
+
+
+def test_bind_host_to_device_keeps_the_thread_runnable():
+    """td_bind_host_to_device: the NUMA node next to GPU 0 (or -1 when the box does not say); whatever it answers, the thread's
+    affinity mask is non-empty and inside the mask it had."""
+    import os
+    from tagdust_amd import lib as tdlib
+    before = os.sched_getaffinity(0)
+    try:
+        node = tdlib.bind_host_to_device(0)
+        after = os.sched_getaffinity(0)
+        assert node >= -1 and len(after) >= 1 and after <= before
+    finally:
+        os.sched_setaffinity(0, before)

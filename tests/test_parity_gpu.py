@@ -488,6 +488,8 @@ def test_full_size_batch_properties(workload, n):
             return c.download() + (c.counts(),)
 
         res, labels, seq, cnt = decode(reads)
+        # the fast paths this model / batch is meant to get are the ones it got
+        assert c.get_option("prune_active") == 1 and c.get_option("spec_lsum_clamped") == 0
         # counters == serial counting over the results
         assert int(cnt[:8].sum()) == n
         for code in range(8):
@@ -500,6 +502,9 @@ def test_full_size_batch_properties(workload, n):
         labels2 = np.zeros(n * (L + 1), np.int8)
         seq2 = np.zeros(n * L, np.uint8)
         c.wait(c.submit(np.ascontiguousarray(reads.reshape(-1)), offs, res=res2, labels=labels2, seq_out=seq2))
+        if workload != "c5":      # (config 5 at this size: HBM holds one 150 GB workspace, not two)
+            c.wait(c.submit(np.ascontiguousarray(reads.reshape(-1)), offs, res=res2, labels=labels2, seq_out=seq2))   # second stream
+            assert c.get_option("overlap_active") == 1
         assert res.tobytes() == res2.tobytes() and np.array_equal(labels, labels2) and np.array_equal(seq, seq2)
         # permutation: tiles hold 64 neighbours; a read must not care who they are
         perm = np.random.default_rng(5).permutation(n)

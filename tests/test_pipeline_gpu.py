@@ -168,6 +168,25 @@ def test_new_entry_points_report_misuse():
         t = c.submit(seq, offs, res=res)          # the context still works afterwards
         c.wait(t)
         assert np.array_equal(res["read_type"], g["read_type"])
+        # a rejected model upload (a ticket is out / an invalid description) leaves the context as it was
+        t3 = c.submit(seq, offs, res=res)
+        with pytest.raises(TdError, match="tickets are outstanding"):
+            c.upload_model(g)
+        c.wait(t3)
+        assert c.last_kernel_ms() >= 0.0          # the batch in flight kept its record
+        badm = dict(g)
+        badm["H"] = int(g["H"]) + 1               # sizes that do not add up
+        badm["label"] = np.concatenate([g["label"], g["label"][:1]])
+        badm["A"] = np.eye(int(g["H"]) + 1, dtype=np.float32)
+        with pytest.raises(TdError, match="inconsistent sizes"):
+            c.upload_model(badm)
+        res[:] = 0
+        c.wait(c.submit(seq, offs, res=res))      # still the old model, no re-upload needed
+        assert np.array_equal(res["read_type"], g["read_type"])
+        with pytest.raises(TdError, match="host_threads"):
+            c.set_option("host_threads", 0)
+        c.set_option("host_threads", 3)
+        assert c.get_option("host_threads") == 3
         with pytest.raises(TdError, match="tickets are outstanding|no batch with ticket"):
             t2 = c.submit(seq, offs, res=res)
             try:
@@ -229,3 +248,40 @@ def test_overlapping_launches_equal_single_stream(overlap):
     finally:
         c.close()
         ref.close()
+
+
+def test_page_locked_input_may_be_reused_after_submit():
+    """td_submit "returns once the reads have left the caller's buffers" -- also when the buffer is page-locked and the DMA
+    engine reads it directly: the producer overwrites its buffer right after every submit, the results are those of the
+    reads it handed over."""
+    from tagdust_amd import RESULT_DTYPE
+    from tagdust_amd.lib import PinnedArray
+    import bench
+    bench.select_workload("c3")
+    g = bench.load_model()
+    n, L = 1 << 18, bench.READ_LEN
+    batches = [bench.synth_batch(n, 4242 + k).reshape(-1) for k in range(3)]
+    offs = np.arange(n + 1, dtype=np.int64) * L
+    c = _ctx(g, 1, depth=3)
+    ref = _ctx(g, 1, depth=1)
+    pin = PinnedArray((n * L,), np.uint8)
+    try:
+        outs, tickets = [], []
+        for b in batches:
+            pin.array[:] = b
+            res = np.zeros(n, RESULT_DTYPE)
+            sq = np.zeros(n * L, np.uint8)
+            outs.append((res, sq))
+            tickets.append(c.submit(pin.array, offs, res=res, seq_out=sq))
+            pin.array[:] = 4                      # the producer refills its buffer: all N
+        for t in tickets:
+            c.wait(t)
+        for b, (res, sq) in zip(batches, outs):
+            ref.upload_batch(b, offs)
+            ref.run()
+            r2, _, s2 = ref.download(labels=False)
+            assert res.tobytes() == r2.tobytes() and np.array_equal(sq, s2)
+    finally:
+        c.close()
+        ref.close()
+        pin.free()

@@ -85,7 +85,8 @@ def test_model_section_states_the_pruned_segments():
 
 # ---------------------------------------------------------------------------------------------------------------------
 def _decode(workload, n, env, stats=True):
-    """One resident batch of a bench workload through a fresh context compiled under `env`; (res, labels, seq, counters)."""
+    """One resident batch of a bench workload through a fresh context compiled under `env`; (res, labels, seq, diagnostic words:
+    td_diag_get, word k = historical slot 192 + k)."""
     import bench
     from tagdust_amd import TagdustHip
     old = {k: os.environ.get(k) for k in env}
@@ -103,7 +104,7 @@ def _decode(workload, n, env, stats=True):
             c.counts_reset()
             c.run()
             res, labels, seq = c.download()
-            return res, labels, seq, c.counts()
+            return res, labels, seq, c.diag()
         finally:
             c.close()
     finally:
@@ -125,7 +126,7 @@ def test_pruned_equals_dense_and_fallbacks(workload, n):
     """Same bytes with pruning off, on, and on with each fall-back route forced: the total_prob check failing for every tile
     (second, dense pass), the spill cut guessed too short (rows missing -> dense pass), a wave giving up after repeated
     failures.  The statistics counters (TD_SPEC_PRUNE_STATS) show which route ran."""
-    S0 = 8 + 232    # counter slots: decisions, sum of required cuts, spill too short, failed checks, tiles, sum of cuts, dense tiles
+    S0 = 232 - 192    # diagnostic words: decisions, sum of required cuts, spill too short, failed checks, tiles, sum of cuts, dense tiles
     dense = _decode(workload, n, {"TD_SPEC_PRUNE": "0", "TD_SPEC_PRUNE_STATS": "0"})
     on = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_STATS": "1"})
     assert _same(dense, on)
@@ -143,10 +144,10 @@ def test_pruned_equals_dense_and_fallbacks(workload, n):
     short = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_STATS": "1", "TD_SPEC_EXTRA_OPTS": "-DTDS_PRUNE_BGAP=-150.0f -DTDS_PRUNE_MARGIN=0"})
     assert _same(dense, short)
     st = short[3][S0:S0 + 8]
-    assert st[2] + short[3][8 + 226] > 0 and st[3] == 0 and st[6] == tiles
+    assert st[2] + short[3][226 - 192] > 0 and st[3] == 0 and st[6] == tiles
     # the trailing segments alone (config 3 and 5 end in a 3' adapter): pruned == dense, the stop lies well inside the read
     if workload != "c2":
-        sfx = on[3][8 + 224:8 + 228]
+        sfx = on[3][224 - 192:228 - 192]
         assert sfx[0] == tiles and sfx[2] == 0 and 30 < sfx[3] / tiles < 140
         only_sfx = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_SFX": "0", "TD_SPEC_PRUNE_STATS": "0"})
         assert _same(dense, only_sfx)

@@ -22,15 +22,15 @@ for prune, stats in ((0, 0), (1, 0), (1, 1), (0, 0), (1, 0)):
     for k in range(5):
         c.counts_reset()
         c.run(); c.sync(); ms.append(c.last_kernel_ms())
-    cnt = c.counts()
+    cnt = c.diag()
     res, labels, seq = c.download()
     note = ""
     if stats:
-        d = cnt[8 + 232:8 + 236]
-        t = cnt[8 + 236:8 + 240]
-        sx = cnt[8 + 224:8 + 228]
-        note = "  trailing: decisions %d (mean required stop %.1f) fall-backs %d mean stop %.1f |" % (sx[0], sx[1] / max(sx[0], 1), sx[2], sx[3] / max(cnt[8 + 236], 1))
-        note += "  lanes failing wa/wb/tot %s" % cnt[8 + 228:8 + 231].tolist()
+        d = cnt[232 - 192:236 - 192]
+        t = cnt[236 - 192:240 - 192]
+        sx = cnt[224 - 192:228 - 192]
+        note = "  trailing: decisions %d (mean required stop %.1f) fall-backs %d mean stop %.1f |" % (sx[0], sx[1] / max(sx[0], 1), sx[2], sx[3] / max(cnt[236 - 192], 1))
+        note += "  lanes failing wa/wb/tot %s" % cnt[228 - 192:231 - 192].tolist()
         note += "  decisions %d (mean required cut %.1f)  spill too short %d  failed checks %d | tiles %d  mean cut %.1f  dense %d  mean spill cut %.1f" % (
             d[0], d[1] / max(d[0], 1), d[2], d[3], t[0], t[1] / max(t[0], 1), t[2], t[3] / max(t[0], 1))
     if base is None:

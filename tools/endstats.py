@@ -16,7 +16,7 @@ for wl, n in (("c3", 1 << 20),):
         c.counts_reset()
         # counters are zeroed by reset: min slots need a large start value -> set via a first run? use max/ sum only
         c.run(); c.sync()
-        k = c.counts()[8 + 200:8 + 206].astype(np.float64)
+        k = c.diag()[200 - 192:206 - 192].astype(np.float64)
         ms = c.last_kernel_ms()
         # min slots are 0 after reset (atomicMin with 0 stays 0): use max start as reference instead
         cc = c.counts()

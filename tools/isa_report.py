@@ -12,6 +12,46 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tools"))
 
 
+# the two VALU issue classes tools/ubench/valu_rate.hip measures on gfx950 (ns per wave64 instruction per SIMD: ~1.0 / ~1.75)
+SLOW_CLASS = ("v_max_f32", "v_min_f32", "v_cvt_i32_f32", "v_lshlrev_b32", "v_cndmask_b32", "v_cmp", "v_fma_f32", "v_med3_f32",
+              "v_pk_add_f32", "v_pk_mul_f32", "v_max3_f32", "v_min3_f32", "v_cvt_")
+
+
+def valu_slow_class_share(name="c3_b6_s_r_p"):
+    """Static instruction mix of the position sweeps (basic blocks of loop depth >= 2) of the kernel compiled for a fixture's
+    model: share of the VALU instructions that belong to the slow issue class.  Instructions the micro-benchmark did not
+    time (v_mov, v_or, v_sub_u32, ...) count as fast, so the class-weighted roofline fraction built on this is a lower bound."""
+    import spec_check
+    out = "/tmp/td_isa_" + name
+    spec_check.check(name, keep=True, outdir=out)
+    asm = [f for f in os.listdir(out) if f.endswith(".s") and "gfx950" in f and f.startswith(name)]
+    depth, in_kernel, n_valu, n_slow = 0, False, 0, 0
+    for l in open(os.path.join(out, asm[0])).read().splitlines():
+        if l.startswith("td_spec_kernel:"):
+            in_kernel = True
+        if l.startswith("td_spec_selfcheck:"):
+            in_kernel = False
+        if not in_kernel:
+            continue
+        if re.match(r"^\.LBB\d+_\d+:", l):
+            depth = 0
+        t = l.strip()
+        if t.startswith(";") or ";" in l and re.match(r"^\.LBB", l):
+            d = None if "Child Loop" in t else re.search(r"Depth[= ](\d+)", l)
+            if d:
+                depth = max(depth, int(d.group(1)))
+            if t.startswith(";"):
+                continue
+        if not t or t.startswith(".") or depth < 2:
+            continue
+        op = t.split()[0]
+        if op.startswith("v_"):
+            n_valu += 1
+            if op.startswith(SLOW_CLASS):
+                n_slow += 1
+    return (n_slow / n_valu) if n_valu else None, n_valu
+
+
 def main():
     import spec_check
     name = sys.argv[1] if len(sys.argv) > 1 else "c3_b6_s_r_p"

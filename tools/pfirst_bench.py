@@ -32,7 +32,7 @@ c.upload_batch(reads.reshape(-1), offs)
 c.run(); c.sync(); c.counts_reset(); c.run(); c.sync()
 print("H", int(md["H"]), "kernel %.1f ms for 2^18 reads -> %.2f M reads/s" % (c.last_kernel_ms(), n / c.last_kernel_ms() / 1e3))
 if os.environ.get("TD_SPEC_PROFILE"):
-    t = c.counts()[8 + 240:8 + 252].astype(np.float64)
+    t = c.diag()[240 - 192:252 - 192].astype(np.float64)
     names = ["unpack", "backward", "forward", "barprob", "labelDP", "traceback", "extraction", "artifacts", "DUST", "outputs", "-", "between"]
     print({nm: round(100 * x / t.sum(), 1) for nm, x in zip(names, t) if x})
 cnt = c.counts(); print("outcomes", cnt[:8].tolist())

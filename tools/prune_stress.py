@@ -44,12 +44,12 @@ for name, (reads, offs) in sets.items():
         ms = []
         for k in range(3):
             c.counts_reset(); c.run(); c.sync(); ms.append(c.last_kernel_ms())
-        cnt = c.counts()
+        cnt = c.diag()
         out[prune] = (min(ms), c.download(), cnt)
         c.close()
     a, b = out[0][1], out[1][1]
     same = a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     cnt = out[1][2]
-    tiles = max(int(cnt[8 + 236]), 1)
+    tiles = max(int(cnt[236 - 192]), 1)
     print(wl + " %-52s off %7.2f ms  on %7.2f ms (x%.2f)  mean cut %5.1f  mean stop %5.1f  dense tiles %d / %d  identical %s" % (
-        name, out[0][0], out[1][0], out[0][0] / out[1][0], cnt[8 + 237] / tiles, cnt[8 + 227] / tiles, cnt[8 + 238], tiles, same), flush=True)
+        name, out[0][0], out[1][0], out[0][0] / out[1][0], cnt[237 - 192] / tiles, cnt[227 - 192] / tiles, cnt[238 - 192], tiles, same), flush=True)
