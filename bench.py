@@ -237,6 +237,49 @@ def cpu_baseline(model, n_sample, seed):
     return out
 
 
+def e2e_stream(dev_index, copies=4, n=1 << 20, n_threads=0, keep_dir=None):
+    """FASTQ file in -> demultiplexed FASTQ files out through the library's streaming pipeline (td_stream_run: parse(k+1) ||
+    decode(k) || write(k-1)) on the bench workload: a file of `copies` x `n` reads (the same synthetic batch
+    written `copies` times), model and threshold given (no calibration in the timed call).  Returns the stage rates."""
+    import tempfile
+    from tagdust_amd import TagdustHip
+    from tagdust_amd import lib as tdlib
+    select_workload("c3")
+    model = load_model()
+    segs = ["B:" + ",".join(BARCODES), "S:" + SPACER, "R:N", "P:" + ADAPTER]
+    with tempfile.TemporaryDirectory(dir=keep_dir) as tmp:
+        one = os.path.join(tmp, "one.fq")
+        _write_fastq(one, synth_batch(n, 4711))
+        text = open(one, "rb").read()
+        fq = os.path.join(tmp, "in.fq")
+        with open(fq, "wb") as fh:
+            for _ in range(copies):
+                fh.write(text)
+        os.remove(one)
+        del text
+        ctx = TagdustHip(dev_index)
+        try:
+            ctx.upload_model(model)
+            ctx.set_params(float(model["threshold"]), 16, 100)
+            tdlib.stream_run(ctx, fq, segs, os.path.join(tmp, "warm"), batch_reads=1 << 16, block_bytes=1 << 22, n_threads=n_threads)   # kernel + buffers warm
+            ctx.counts_reset()
+            st = tdlib.stream_run(ctx, fq, segs, os.path.join(tmp, "out"), n_threads=n_threads)
+            cnt = ctx.counts()
+        finally:
+            ctx.close()
+        out_bytes = sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp) if f.startswith("out"))
+    r = st["n_reads"]
+    rate = lambda sec: (r / sec) if sec > 0 else None
+    return {"reads": r, "batches": st["n_batches"], "fastq_bytes_in": st["bytes_in"], "fastq_bytes_out": st["bytes_out"],
+            "files_bytes_on_disk": out_bytes, "counters_add_up": bool(int(cnt[:8].sum()) == r),
+            "wall_s": st["wall_s"], "value": rate(st["wall_s"]), "unit": "reads/s",
+            "parse_stage_reads_per_s": rate(st["parse_s"]), "write_stage_reads_per_s": rate(st["write_s"]),
+            "decode_thread_busy_s": st["decode_s"], "parse_busy_s": st["parse_s"], "write_busy_s": st["write_s"], "read_wait_s": st["read_s"],
+            "wall_over_slowest_host_stage": (max(st["parse_s"], st["write_s"]) / st["wall_s"]) if st["wall_s"] > 0 else None,
+            "what": "td_stream_run on a %d x %d-read FASTQ file in a temporary directory (page cache), batches of 1 000 001 reads, "
+                    "model + threshold given; wall includes opening the files and allocating the page-locked batch buffers" % (copies, n)}
+
+
 class _DevCounters:
     """The library's device counters (td_counts_device_ptr) as a CUDA-array-interface object, so that torch can wrap them
     without a copy and RCCL reduces them in place."""
@@ -662,6 +705,10 @@ def main():
             except SystemExit as e:
                 extra[key] = {"error": str(e)}
         select_workload(args.workload)
+        try:
+            extra["e2e"] = e2e_stream(dev_index)
+        except Exception as e:      # the end-to-end extra must not take the bench line down
+            extra["e2e"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         out["extra"] = extra
         if args.cpu_sample and world == 1:

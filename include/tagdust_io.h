@@ -58,6 +58,33 @@ int  td_writer_open(const char* out_prefix, const td_arch* arch, td_writer** out
 int  td_writer_write(td_writer* w, const td_reads* reads, const td_read_result* res, const uint8_t* seq_out);
 int  td_writer_close(td_writer* w);
 
+/* ---- one input file of any size as a pipeline: the reference's batch loop around run_pHMM (src/barcode_hmm.c:244-385) ----
+ * read_fasta_fastq() of <= 1 000 001 records (io.c:1684-1815; plain files, or zcat / bzcat through popen like io_handler(),
+ * io.c:382-608, by the file name's suffix; "-" = stdin) -> td_submit / td_wait on `ctx` (model, parameters, artifact filter
+ * and window as set by the caller; TD_MODE_GET_LABEL) -> print_all()'s per-barcode appends (io.c:757-1016), with the three
+ * steps of consecutive batches side by side: a reader/parser thread fills the next batch's page-locked buffers (records
+ * found and base-coded by n_threads threads), the calling thread drives the device ("pipeline_depth" batches in flight), a
+ * writer thread formats and appends finished batches (n_threads threads; every output file keeps input order).  A plain
+ * file is mapped, not read.  Batches hold exactly batch_reads records like the reference's, whatever the block size.
+ * The output files are those td_writer_open names, byte for byte what td_reads_parse / td_writer_write give for the whole
+ * text at once.  ctx == NULL: a parse-only run (no GPU, nothing written) that fills stats, codes_fnv included. */
+typedef struct td_stream_opts {
+	int32_t batch_reads;   /* records per batch; 0 = 1 000 001 (param->num_query, src/barcode_hmm.c:172) */
+	int32_t n_threads;     /* host threads of the parse stage and of the write stage, each; 0 = pick (<= 8) */
+	int64_t block_bytes;   /* bytes of input taken at a time; 0 = 64 MiB */
+} td_stream_opts;
+typedef struct td_stream_stats {
+	int64_t n_reads, n_batches, bytes_in, bytes_out;
+	double  wall_s;        /* the whole call */
+	double  read_s;        /* waiting for input bytes (pipes; a mapped file is paged in by the parse threads) */
+	double  parse_s;       /* parse stage busy: records, batch assembly, base coding */
+	double  decode_s;      /* calling thread inside td_submit / td_wait */
+	double  write_s;       /* write stage busy: formatting + appends */
+	uint64_t codes_fnv;    /* parse-only runs: FNV-1a over (read length, base codes) of all reads in order; else 0 */
+} td_stream_stats;
+int td_stream_run(td_ctx* ctx, const char* in_path, const td_arch* arch, const char* out_prefix,
+                  const td_stream_opts* opts, td_stream_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,13 +10,19 @@
  * writes the results back into struct read_info exactly where do_label_thread / do_probability_estimation leave
  * them (mapq, labels, read_type, barcode, fingerprint, seq/qual rewritten in place, bar_prob = 100).
  *
- * What the GPU path does not cover is passed to the reference's own CPU implementation, which the build recipe keeps
- * available as ref_run_pHMM() (oracle/Makefile): the dead training modes, and a -start/-end batch in which a read is
- * shorter than matchend (the reference then reads past the end of that read -- undefined behaviour only its own code can
- * "reproduce"; windows as such run on the GPU).  Every such hand-over is counted, and at exit the shim reports
+ * Every mode the live reference calls (MODE_GET_LABEL, MODE_GET_PROB, MODE_ARCH_COMP), with and without -start/-end windows,
+ * runs on the GPU.  What is left for the reference's own CPU implementation -- which the build recipe keeps available as
+ * ref_run_pHMM() (oracle/Makefile) -- are the training modes (dead code in v2.33, unreachable from its CLI) and whatever
+ * mode TAGDUST_HIP_DELEGATE=<mode>[,<mode>] names (a debugging aid: e.g. "4" runs the threshold calibration on the CPU and
+ * the labelling on the GPU inside one binary).  Every hand-over is counted, and at exit the shim reports
  *     tagdust_hip: batches gpu=<n> delegated=<m>
  * on stderr.  TAGDUST_HIP_STRICT=1 turns a hand-over into an error (run_pHMM returns kslFAIL with a message), so that a
  * test -- or a user -- can be sure that every result came from the GPU.
+ *
+ * Inputs on which the reference itself has no defined behaviour are not handed to it: a -start/-end window with
+ * start < 0 or end <= start (the reference decodes a negative length and crashes) is refused with a message, and a read
+ * shorter than -end (the reference reads past its end and corrupts its heap: "munmap_chunk(): invalid pointer") is decoded
+ * on the bases it has inside the window, like td_set_window documents.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -250,12 +256,21 @@ int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, s
 	if (mode != MODE_GET_LABEL && mode != MODE_GET_PROB && mode != MODE_ARCH_COMP)
 		return delegate("a training mode (dead code in v2.33)", ab, mb, ri, param, reference_fasta, numseq, mode);
 	if (mode == MODE_ARCH_COMP && !ab) return delegate("architecture comparison without candidates", ab, mb, ri, param, reference_fasta, numseq, mode);
-	if (windowed && mode == MODE_ARCH_COMP) return delegate("architecture comparison inside a -start/-end window", ab, mb, ri, param, reference_fasta, numseq, mode);
-	if (windowed) {
-		if (param->matchstart < 0 || param->matchend <= param->matchstart)
-			return delegate("a -start/-end window with start < 0 or end <= start", ab, mb, ri, param, reference_fasta, numseq, mode);
-		for (i = 0; i < numseq; i++) if (ri[i]->len < param->matchend)
-			return delegate("a read shorter than -end (the reference reads past its end)", ab, mb, ri, param, reference_fasta, numseq, mode);
+	{
+		const char* d = getenv("TAGDUST_HIP_DELEGATE");      /* "4" / "1,4": these modes go to the reference's code (A/B aid) */
+		while (d && *d) {
+			char* end = NULL;
+			const long v = strtol(d, &end, 10);
+			if (end == d) break;
+			if (v == mode) return delegate("TAGDUST_HIP_DELEGATE names this mode", ab, mb, ri, param, reference_fasta, numseq, mode);
+			d = end;
+			while (*d == ',' || *d == ' ') d++;
+		}
+	}
+	/* (do_arch_comparison scores whole reads whatever -start/-end say, barcode_hmm.c:2111-2148: so does arch_comparison below) */
+	if (windowed && mode != MODE_ARCH_COMP && (param->matchstart < 0 || param->matchend <= param->matchstart)) {
+		fprintf(stderr, "tagdust_hip: -start %d -end %d is not a window (need 1 <= start <= end; both must be given)\n", param->matchstart + 1, param->matchend);
+		return kslFAIL;
 	}
 	if (numseq <= 0) return kslOK;
 

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/tagdust_io.h"
+#include "td_io_internal.h"
 
 namespace {
 
@@ -24,12 +25,30 @@ struct Code {
 };
 const Code kCode;
 
-struct Rec { int64_t name_off; int32_t name_len; int64_t seq_off; int32_t seq_len; int64_t qual_off; int32_t qual_len; };
+typedef TdRec Rec;
 
 thread_local std::string g_io_error;
 
+// length of the field starting at p: up to the first control character, at most n bytes.  Lines almost never hold one before
+// their end, so the bytes are tested sixteen at a time (the loop body vectorises) and walked one by one only where one is.
+inline int32_t field_len_fast(const char* p, int64_t n)
+{
+	int64_t q = 0;
+	for (; q + 16 <= n; q += 16) {
+		unsigned any = 0;
+		for (int k = 0; k < 16; k++) { const unsigned char ch = (unsigned char)p[q + k]; any |= (unsigned)(ch < 32) | (unsigned)(ch == 127); }
+		if (any) break;
+	}
+	while (q < n && !is_cntrl((unsigned char)p[q])) q++;
+	return (int32_t)q;
+}
+
+} // namespace
+
+void td_io_set_error(const std::string& msg) { g_io_error = msg; }
+
 // read_fasta_fastq()'s line state machine (io.c:1697-1799) over text[lo, hi); lo must be the start of a line
-void parse_range(const char* text, int64_t lo, int64_t hi, std::vector<Rec>& out)
+void td_parse_range(const char* text, int64_t lo, int64_t hi, std::vector<TdRec>& out)
 {
 	bool set = false, seq_p = false;
 	int64_t p = lo;
@@ -37,7 +56,7 @@ void parse_range(const char* text, int64_t lo, int64_t hi, std::vector<Rec>& out
 		const char* nl = (const char*)memchr(text + p, '\n', (size_t)(hi - p));
 		const int64_t e = nl ? (nl - text) : hi; // line = [p, e)
 		const char first = (p < e) ? text[p] : '\n';
-		auto field_len = [&](int64_t from) { int64_t q = from; while (q < e && !is_cntrl((unsigned char)text[q])) q++; return (int32_t)(q - from); };
+		auto field_len = [&](int64_t from) { return field_len_fast(text + from, e - from); };
 		if ((first == '@' || first == '>') && !set) {
 			Rec r; r.name_off = p + 1; r.name_len = field_len(p + 1); r.seq_off = -1; r.seq_len = 0; r.qual_off = -1; r.qual_len = 0;
 			out.push_back(r);
@@ -55,7 +74,32 @@ void parse_range(const char* text, int64_t lo, int64_t hi, std::vector<Rec>& out
 	}
 }
 
-} // namespace
+extern const uint8_t* const td_nuc_code_ptr;
+const uint8_t* const td_nuc_code_ptr = kCode.t;
+
+int64_t td_next_record_start(const char* text, int64_t len, int64_t from, bool fasta)
+{
+	// FASTQ: a line starting with '@' whose line after next starts with '+' (a quality line may start with '@', but then the
+	// line after next is a sequence, which cannot start with '+').  FASTA: any line starting with '>'.
+	int64_t p = from;
+	if (p <= 0) return 0;
+	if (text[p - 1] != '\n') {   // to the start of the next line
+		const char* nl = (const char*)memchr(text + p, '\n', (size_t)(len - p));
+		if (!nl) return len;
+		p = nl - text + 1;
+	}
+	while (p < len) {
+		const char* nl1 = (const char*)memchr(text + p, '\n', (size_t)(len - p));
+		if (!nl1) return len;
+		if (fasta && text[p] == '>') return p;
+		if (!fasta && text[p] == '@') {
+			const char* nl2 = (const char*)memchr(nl1 + 1, '\n', (size_t)(len - (nl1 + 1 - text)));
+			if (nl2 && nl2 + 1 < text + len && nl2[1] == '+') return p;
+		}
+		p = nl1 - text + 1;
+	}
+	return len;
+}
 
 extern "C" int td_reads_parse(const char* text, int64_t len, int32_t n_threads, td_reads** out)
 {
@@ -68,29 +112,16 @@ extern "C" int td_reads_parse(const char* text, int64_t len, int32_t n_threads, 
 	const bool fasta = len > 0 && text[0] == '>';
 	std::vector<int64_t> cut(1, 0);
 	for (int t = 1; t < n_threads; t++) {
-		int64_t p = len / n_threads * t;
-		while (p < len && text[p] != '\n') p++;
-		p++;
-		bool found = false;
-		for (int tries = 0; tries < 64 && p < len; tries++) {
-			const char* nl1 = (const char*)memchr(text + p, '\n', (size_t)(len - p));
-			if (!nl1) break;
-			if (fasta && text[p] == '>') { found = true; break; }
-			if (!fasta && text[p] == '@') {
-				const char* nl2 = (const char*)memchr(nl1 + 1, '\n', (size_t)(len - (nl1 + 1 - text)));
-				if (nl2 && nl2 + 1 < text + len && nl2[1] == '+') { found = true; break; }
-			}
-			p = nl1 - text + 1;
-		}
-		if (found && p > cut.back()) cut.push_back(p);
+		const int64_t p = td_next_record_start(text, len, len / n_threads * t, fasta);
+		if (p < len && p > cut.back()) cut.push_back(p);
 	}
 	cut.push_back(len);
 	const int nchunk = (int)cut.size() - 1;
 	std::vector<std::vector<Rec>> recs((size_t)nchunk);
 	{
 		std::vector<std::thread> th;
-		for (int k = 1; k < nchunk; k++) th.emplace_back(parse_range, text, cut[(size_t)k], cut[(size_t)k + 1], std::ref(recs[(size_t)k]));
-		parse_range(text, cut[0], cut[1], recs[0]);
+		for (int k = 1; k < nchunk; k++) th.emplace_back(td_parse_range, text, cut[(size_t)k], cut[(size_t)k + 1], std::ref(recs[(size_t)k]));
+		td_parse_range(text, cut[0], cut[1], recs[0]);
 		for (auto& t : th) t.join();
 	}
 	int64_t n = 0;
@@ -162,27 +193,33 @@ struct td_writer {
 	int num_out_reads = 1;
 };
 
-extern "C" int td_writer_open(const char* prefix, const td_arch* a, td_writer** out)
+void td_writer_file_names(const char* prefix, const td_arch* a, std::vector<std::string>& names, int* num_alternatives)
 {
-	if (!prefix || !a || !out) return TD_FAIL;
-	td_writer* w = new td_writer();
 	int barsegment = -1, n_r = 0;
 	for (int i = 0; i < a->n_segments; i++) {
 		if (a->type[i] == 'B' && barsegment < 0) barsegment = i;
 		if (a->type[i] == 'R') n_r++;
 	}
-	w->num_out_reads = n_r;
-	w->num_alternatives = barsegment >= 0 ? a->n_seq[barsegment] : 2;
-	std::vector<std::string> names;
+	const int alt = barsegment >= 0 ? a->n_seq[barsegment] : 2;
+	if (num_alternatives) *num_alternatives = alt;
+	names.clear();
 	for (int i = 0; i < n_r; i++) { // io.c:859-915
 		const std::string rd = n_r > 1 ? "_READ" + std::to_string(i + 1) : "";
 		if (barsegment >= 0) {
-			for (int j = 0; j < w->num_alternatives - 1; j++) names.push_back(std::string(prefix) + "_BC_" + a->seqs[barsegment][j] + rd + ".fq");
+			for (int j = 0; j < alt - 1; j++) names.push_back(std::string(prefix) + "_BC_" + a->seqs[barsegment][j] + rd + ".fq");
 		} else {
 			names.push_back(std::string(prefix) + rd + ".fq");
 		}
 		names.push_back(std::string(prefix) + "_un" + rd + ".fq");
 	}
+}
+
+extern "C" int td_writer_open(const char* prefix, const td_arch* a, td_writer** out)
+{
+	if (!prefix || !a || !out) return TD_FAIL;
+	td_writer* w = new td_writer();
+	std::vector<std::string> names;
+	td_writer_file_names(prefix, a, names, &w->num_alternatives);
 	for (auto& nm : names) {
 		FILE* f = fopen(nm.c_str(), "w");
 		if (!f) { for (FILE* g : w->files) fclose(g); delete w; return TD_FAIL; }

@@ -1,0 +1,646 @@
+// td_stream.cpp -- one input file of any size through the decode path as a pipeline (include/tagdust_io.h, td_stream_run):
+//
+//   reader / parser thread            caller's thread                     writer thread
+//   block k+1: read or map, find      batch k: td_submit ... td_wait      batch k-1: format per output file, append
+//   records, base-code them into      (several batches in flight on the
+//   the next batch's pinned buffers   device)
+//
+// It replaces the reference's batch loop around run_pHMM for one file (src/barcode_hmm.c:244-385): read_fasta_fastq() of
+// <= 1 000 001 records (io.c:1684-1815, through popen("cat|zcat|bzcat"), io.c:382-608) -> run_pHMM -> print_all() appending
+// to the per-barcode files (io.c:757-1016) -- with the three steps of consecutive batches running side by side, each of the
+// two host steps on several threads.  Batches hold exactly `batch_reads` records like the reference's (the -ref artifact
+// filter's per-thread read ranges are taken over a batch, barcode_hmm.c:2478-2583, so the boundaries are part of the result).
+#include <errno.h>
+#include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/tagdust_io.h"
+#include "td_io_internal.h"
+
+namespace {
+
+double now_s()
+{
+	return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- a few persistent threads that run task(k) for k in [0, n) ----
+class Pool {
+public:
+	explicit Pool(int n_threads)
+	{
+		for (int t = 1; t < n_threads; t++) th_.emplace_back([this] { worker(); });
+	}
+	~Pool()
+	{
+		{ std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+		cv_.notify_all();
+		for (auto& t : th_) t.join();
+	}
+	int size() const { return (int)th_.size() + 1; }
+	void run(int64_t n, const std::function<void(int64_t)>& task)
+	{
+		if (n <= 0) return;
+		if (th_.empty() || n == 1) { for (int64_t k = 0; k < n; k++) task(k); return; }
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			task_ = &task; next_ = 0; n_ = n; left_ = n; gen_++;
+		}
+		cv_.notify_all();
+		drain();                               // the calling thread takes tasks too
+		std::unique_lock<std::mutex> lk(mu_);
+		done_.wait(lk, [this] { return left_ == 0; });
+		task_ = nullptr;
+	}
+
+private:
+	void drain()
+	{
+		for (;;) {
+			int64_t k;
+			const std::function<void(int64_t)>* t;
+			{
+				std::lock_guard<std::mutex> lk(mu_);
+				if (!task_ || next_ >= n_) return;
+				k = next_++; t = task_;
+			}
+			(*t)(k);
+			std::lock_guard<std::mutex> lk(mu_);
+			if (--left_ == 0) done_.notify_all();
+		}
+	}
+	void worker()
+	{
+		uint64_t seen = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> lk(mu_);
+				cv_.wait(lk, [&] { return stop_ || (gen_ != seen && task_); });
+				if (stop_) return;
+				seen = gen_;
+			}
+			drain();
+		}
+	}
+	std::vector<std::thread> th_;
+	std::mutex mu_;
+	std::condition_variable cv_, done_;
+	const std::function<void(int64_t)>* task_ = nullptr;
+	int64_t next_ = 0, n_ = 0, left_ = 0;
+	uint64_t gen_ = 0;
+	bool stop_ = false;
+};
+
+// ---- bounded FIFO between the stages ----
+template <typename T>
+class Queue {
+public:
+	explicit Queue(size_t cap) : cap_(cap) {}
+	bool push(T v)          // false: the pipeline was aborted
+	{
+		std::unique_lock<std::mutex> lk(mu_);
+		cv_.wait(lk, [&] { return abort_ || q_.size() < cap_; });
+		if (abort_) return false;
+		q_.push_back(std::move(v));
+		cv_.notify_all();
+		return true;
+	}
+	bool pop(T& v)          // false: closed and empty, or aborted
+	{
+		std::unique_lock<std::mutex> lk(mu_);
+		cv_.wait(lk, [&] { return abort_ || closed_ || !q_.empty(); });
+		if (abort_ || q_.empty()) return false;
+		v = std::move(q_.front());
+		q_.pop_front();
+		cv_.notify_all();
+		return true;
+	}
+	void close() { std::lock_guard<std::mutex> lk(mu_); closed_ = true; cv_.notify_all(); }
+	void abort() { std::lock_guard<std::mutex> lk(mu_); abort_ = true; cv_.notify_all(); }
+
+private:
+	std::mutex mu_;
+	std::condition_variable cv_;
+	std::deque<T> q_;
+	size_t cap_;
+	bool closed_ = false, abort_ = false;
+};
+
+// ---- input text: one mapping of a plain file, or blocks read from a pipe ----
+struct Block {
+	const char* data = nullptr;
+	int64_t len = 0;
+	char* owned = nullptr;          // malloc'ed (pipe input); a mapped file is owned by the Source
+	~Block() { free(owned); }
+};
+
+class Source {
+public:
+	~Source()
+	{
+		if (map_ && map_ != MAP_FAILED) munmap(map_, (size_t)map_len_);
+		if (pipe_) pclose(pipe_);
+		if (fd_ >= 0) close(fd_);
+	}
+	bool open(const char* path, int64_t block_bytes, std::string& err)
+	{
+		block_ = block_bytes;
+		const std::string p = path;
+		auto ends = [&](const char* sfx) { const size_t n = strlen(sfx); return p.size() >= n && p.compare(p.size() - n, n, sfx) == 0; };
+		struct stat st;
+		if (p != "-" && stat(path, &st) != 0) { err = "td_stream_run: cannot find input file " + p; return false; }
+		if (ends(".sam") || ends(".bam") || ends(".sam.gz") || ends(".bam.gz")) { err = "td_stream_run: SAM/BAM input is not supported (FASTQ/FASTA only): " + p; return false; }
+		if (ends(".gz") || ends(".bz2")) {             // io_handler(), io.c:382-608: zcat / bzcat through popen
+			std::string q;
+			for (char ch : p) { if (ch == '\'') q += "'\\''"; else q += ch; }
+			const std::string cmd = std::string(ends(".gz") ? "zcat" : "bzcat") + " -- '" + q + "'";
+			pipe_ = popen(cmd.c_str(), "r");
+			if (!pipe_) { err = "td_stream_run: cannot start " + cmd; return false; }
+			fd_in_ = fileno(pipe_);
+			return true;
+		}
+		if (p == "-") { fd_in_ = 0; return true; }
+		fd_ = ::open(path, O_RDONLY);
+		if (fd_ < 0) { err = "td_stream_run: cannot open " + p + ": " + strerror(errno); return false; }
+		if (S_ISREG(st.st_mode)) {
+			map_len_ = st.st_size;
+			if (map_len_ == 0) { eof_ = true; return true; }
+			map_ = mmap(nullptr, (size_t)map_len_, PROT_READ, MAP_PRIVATE, fd_, 0);
+			if (map_ != MAP_FAILED) {
+				(void)madvise(map_, (size_t)map_len_, MADV_SEQUENTIAL);
+				fasta_ = ((const char*)map_)[0] == '>';
+				return true;
+			}
+			map_ = nullptr;                            // fall back to read()
+		}
+		fd_in_ = fd_;
+		return true;
+	}
+	// the next block of whole records (nullptr at the end); *read_s += time spent waiting for bytes
+	std::shared_ptr<Block> next(double* read_s, std::string& err)
+	{
+		if (eof_) return nullptr;
+		auto b = std::make_shared<Block>();
+		if (map_) {
+			const char* text = (const char*)map_;
+			int64_t end = map_pos_ + block_;
+			end = end >= map_len_ ? map_len_ : td_next_record_start(text, map_len_, end, fasta_);
+			b->data = text + map_pos_; b->len = end - map_pos_;
+			(void)madvise((void*)((uintptr_t)(text + map_pos_) & ~(uintptr_t)4095), (size_t)(b->len + 4096), MADV_WILLNEED);
+			map_pos_ = end;
+			if (map_pos_ >= map_len_) eof_ = true;
+			return b;
+		}
+		// pipe / stdin: fill a buffer, cut it at the last record start found in its tail, carry the rest over
+		const double t0 = now_s();
+		const int64_t cap = block_ + (int64_t)carry_.size() + 1;
+		b->owned = (char*)malloc((size_t)cap);
+		if (!b->owned) { err = "td_stream_run: out of memory"; return nullptr; }
+		int64_t have = (int64_t)carry_.size();
+		if (have) memcpy(b->owned, carry_.data(), (size_t)have);
+		carry_.clear();
+		bool end_of_input = false;
+		while (have < cap - 1) {
+			const ssize_t r = read(fd_in_, b->owned + have, (size_t)(cap - 1 - have));
+			if (r < 0) { if (errno == EINTR) continue; err = std::string("td_stream_run: read failed: ") + strerror(errno); return nullptr; }
+			if (r == 0) { end_of_input = true; break; }
+			have += r;
+		}
+		*read_s += now_s() - t0;
+		if (first_block_) { fasta_ = have > 0 && b->owned[0] == '>'; first_block_ = false; }
+		int64_t cut = have;
+		if (!end_of_input) {
+			// the last record start in the buffer: search forward from ever earlier points of the tail
+			cut = -1;
+			for (int64_t back = 1 << 16; cut < 0; back *= 4) {
+				int64_t from = have - back;
+				if (from < 1) from = 1;
+				int64_t p = td_next_record_start(b->owned, have, from, fasta_), last = -1;
+				while (p < have) { last = p; p = td_next_record_start(b->owned, have, p + 1, fasta_); }
+				if (last > 0) cut = last;
+				else if (from == 1) { err = "td_stream_run: no record boundary within a block of input (raise block_bytes)"; return nullptr; }
+			}
+			carry_.assign(b->owned + cut, b->owned + have);
+		} else {
+			eof_ = true;
+		}
+		b->data = b->owned; b->len = cut;
+		if (cut == 0 && eof_) return nullptr;
+		return b;
+	}
+
+private:
+	int fd_ = -1, fd_in_ = -1;
+	FILE* pipe_ = nullptr;
+	void* map_ = nullptr;
+	int64_t map_len_ = 0, map_pos_ = 0, block_ = 0;
+	bool eof_ = false, fasta_ = false, first_block_ = true;
+	std::vector<char> carry_;
+};
+
+// ---- a decode batch: exactly batch_reads records (fewer at the end), device-ready buffers in page-locked memory ----
+struct Piece {                      // records [lo, hi) of one parsed chunk of a block
+	std::shared_ptr<Block> blk;
+	std::shared_ptr<std::vector<TdRec>> recs;
+	int64_t lo = 0, hi = 0;
+	int64_t first = 0;              // index of record lo within the batch
+};
+
+struct Batch {
+	int64_t n = 0, n_bases = 0;
+	uint8_t* codes = nullptr;  size_t cap_codes = 0;
+	uint8_t* seq_out = nullptr; size_t cap_seq = 0;
+	int64_t* offs = nullptr;
+	td_read_result* res = nullptr;
+	std::vector<Piece> pieces;
+	int64_t ticket = 0;
+	bool last = false;
+};
+
+// batch buffers: page-locked for the device; plain memory for a parse-only run (no GPU runtime needed then)
+void* buf_alloc(bool dry, size_t bytes) { return dry ? malloc(bytes ? bytes : 1) : td_host_alloc(bytes); }
+void buf_free(bool dry, void* p) { if (dry) free(p); else td_host_free(p); }
+
+bool grow_buf(bool dry, uint8_t** p, size_t* cap, size_t need, size_t keep)
+{
+	if (*cap >= need) return true;
+	size_t want = need + need / 4 + 4096;
+	uint8_t* q = (uint8_t*)buf_alloc(dry, want);
+	if (!q) return false;
+	if (*p && keep) memcpy(q, *p, keep);
+	if (*p) buf_free(dry, *p);
+	*p = q; *cap = want;
+	return true;
+}
+
+// formats the records of one piece sub-range into one buffer per output file (print_all(), io.c:917-1001)
+struct OutBufs { std::vector<std::string> file; };
+
+void format_records(const Batch& b, const Piece& pc, int64_t lo, int64_t hi, int num_alternatives, OutBufs& out)
+{
+	static const char alphabet[] = "ACGTNN";
+	const char* text = pc.blk->data;
+	const std::vector<TdRec>& recs = *pc.recs;
+	char head[64];
+	const size_t n_files = out.file.size();
+	std::string seq, qual;
+	for (int64_t r = lo; r < hi; r++) {
+		const TdRec& rec = recs[(size_t)r];
+		const int64_t i = pc.first + (r - pc.lo);             // index in the batch
+		const td_read_result& rr = b.res[i];
+		size_t f;                                              // io.c:923-934
+		if (rr.read_type == TD_EXTRACT_SUCCESS) f = (rr.barcode != -1) ? (size_t)(rr.barcode & 0xFF) : 0;
+		else f = (size_t)num_alternatives - 1;
+		const uint8_t* s = b.seq_out + b.offs[i];
+		const int64_t len = b.offs[i + 1] - b.offs[i];
+		const char* q = rec.qual_off >= 0 ? text + rec.qual_off : nullptr;
+		int head_len = -1;
+		int64_t g = 0;
+		while (g < len) {
+			while (g < len && s[g] >= 5) g++;                  // removed positions (65) split the read into records
+			const int64_t g0 = g;
+			while (g < len && s[g] < 5) g++;
+			if (g == g0) break;
+			if (f < n_files) {                                 // io.c:955-975
+				std::string& o = out.file[f];
+				if (head_len < 0) {
+					int k = 0;
+					if (rr.fingerprint != -1) k = snprintf(head, sizeof head, ";FP:%d", rr.fingerprint);
+					k += snprintf(head + k, sizeof head - (size_t)k, ";RQ:%0.2f\n", (double)rr.mapq);
+					head_len = k;
+				}
+				const size_t run = (size_t)(g - g0);
+				const size_t at = o.size();
+				o.resize(at + 1 + (size_t)rec.name_len + (size_t)head_len + run + 3 + run + 1);
+				char* w = &o[at];
+				*w++ = '@';
+				memcpy(w, text + rec.name_off, (size_t)rec.name_len); w += rec.name_len;
+				memcpy(w, head, (size_t)head_len); w += head_len;
+				for (size_t k = 0; k < run; k++) w[k] = alphabet[s[g0 + (int64_t)k]];
+				w += run;
+				*w++ = '\n'; *w++ = '+'; *w++ = '\n';
+				if (q) memcpy(w, q + g0, run); else memset(w, '.', run);
+				w += run;
+				*w++ = '\n';
+			}
+			f += (size_t)num_alternatives;
+		}
+	}
+}
+
+struct Pipeline {
+	td_ctx* ctx = nullptr;
+	const td_arch* arch = nullptr;
+	td_stream_opts o{};
+	td_stream_stats st{};
+	Source src;
+	std::string err;
+	std::mutex err_mu;
+	std::unique_ptr<Pool> parse_pool, write_pool;
+	std::unique_ptr<Queue<Batch*>> ready, done, free_list;
+	std::vector<Batch*> all;
+	std::vector<int> fds;
+	std::vector<int64_t> file_off;
+	int num_alternatives = 2;
+	bool dry = false;
+	uint64_t fnv = 1469598103934665603ULL;
+
+	void fail(const std::string& m)
+	{
+		{ std::lock_guard<std::mutex> lk(err_mu); if (err.empty()) err = m; }
+		ready->abort(); done->abort(); free_list->abort();
+	}
+	bool failed() { std::lock_guard<std::mutex> lk(err_mu); return !err.empty(); }
+
+	Batch* new_batch()
+	{
+		Batch* b = new Batch();
+		b->offs = (int64_t*)buf_alloc(dry, sizeof(int64_t) * ((size_t)o.batch_reads + 1));
+		b->res = (td_read_result*)buf_alloc(dry, sizeof(td_read_result) * (size_t)o.batch_reads);
+		if (!b->offs || !b->res) { buf_free(dry, b->offs); buf_free(dry, b->res); delete b; return nullptr; }
+		b->offs[0] = 0;
+		all.push_back(b);
+		return b;
+	}
+
+	// ---- stage 1: read / map a block, find its records, hand them out to batches, base-code them ----
+	void producer()
+	{
+		Batch* cur = nullptr;
+		const int P = parse_pool->size();
+		for (;;) {
+			std::string e;
+			std::shared_ptr<Block> blk = src.next(&st.read_s, e);
+			if (!blk) { if (!e.empty()) { fail(e); return; } break; }
+			const double t0 = now_s();
+			st.bytes_in += blk->len;
+			// records: P chunks cut at record starts, each parsed by the reference's line state machine
+			const bool fasta = blk->len > 0 && blk->data[0] == '>';
+			std::vector<int64_t> cut(1, 0);
+			const int nchunk_want = blk->len < (1 << 20) ? 1 : P * 4;
+			for (int t = 1; t < nchunk_want; t++) {
+				const int64_t p = td_next_record_start(blk->data, blk->len, blk->len / nchunk_want * t, fasta);
+				if (p < blk->len && p > cut.back()) cut.push_back(p);
+			}
+			cut.push_back(blk->len);
+			const int nchunk = (int)cut.size() - 1;
+			std::vector<std::shared_ptr<std::vector<TdRec>>> recs((size_t)nchunk);
+			for (auto& r : recs) r = std::make_shared<std::vector<TdRec>>();
+			std::vector<int64_t> bad((size_t)nchunk, -1);
+			parse_pool->run(nchunk, [&](int64_t k) {
+				std::vector<TdRec>& v = *recs[(size_t)k];
+				v.reserve((size_t)((cut[(size_t)k + 1] - cut[(size_t)k]) / 200 + 16));
+				td_parse_range(blk->data, cut[(size_t)k], cut[(size_t)k + 1], v);
+				// "Length of sequence and base qualities differ" ends the reference's run (io.c:1776-1781)
+				for (size_t i = 0; i < v.size(); i++)
+					if (v[i].qual_off >= 0 && v[i].qual_len != (v[i].seq_off >= 0 ? v[i].seq_len : 0)) { bad[(size_t)k] = (int64_t)i; break; }
+			});
+			for (int k = 0; k < nchunk; k++)
+				if (bad[(size_t)k] >= 0) {
+					const TdRec& q = (*recs[(size_t)k])[(size_t)bad[(size_t)k]];
+					char msg[256];
+					snprintf(msg, sizeof msg, "td_stream_run: record \"%.*s\": sequence has %d characters, base qualities %d",
+					         q.name_len < 60 ? q.name_len : 60, blk->data + q.name_off, q.seq_off >= 0 ? q.seq_len : 0, q.qual_len);
+					fail(msg);
+					return;
+				}
+			// hand the records out to batches of exactly batch_reads, in order (offsets by a running sum); the pieces handed out
+			// are base-coded (init_nuc_code) in parallel and full batches passed on whenever two are waiting, and before this
+			// thread might have to wait for a free batch
+			struct Job { Batch* b; size_t piece; };
+			std::vector<Job> jobs;
+			std::vector<Batch*> full;
+			const uint8_t* code = td_nuc_code_ptr;
+			double t_seg = t0;
+			auto flush = [&]() -> bool {
+				std::vector<Batch*> touched = full;
+				if (cur) touched.push_back(cur);
+				for (Batch* b : touched) {
+					// page-locked room for the codes going in and the rewritten sequences coming back (bases of earlier pieces of
+					// a batch are already encoded: keep them)
+					bool mine = false;
+					size_t keep = 0;
+					for (const Job& j : jobs) if (j.b == b) { keep = (size_t)b->offs[b->pieces[j.piece].first]; mine = true; break; }
+					if (!mine) continue;
+					if (!grow_buf(dry, &b->codes, &b->cap_codes, (size_t)b->n_bases + 1, keep) ||
+					    !grow_buf(dry, &b->seq_out, &b->cap_seq, (size_t)b->n_bases + 1, 0)) { fail("td_stream_run: page-locked memory exhausted"); return false; }
+				}
+				struct Sub { Batch* b; size_t piece; int64_t lo, hi; };
+				std::vector<Sub> subs;
+				for (const Job& j : jobs) {
+					const Piece& pc = j.b->pieces[j.piece];
+					for (int64_t a = pc.lo; a < pc.hi; a += 16384) subs.push_back(Sub{ j.b, j.piece, a, std::min<int64_t>(a + 16384, pc.hi) });
+				}
+				parse_pool->run((int64_t)subs.size(), [&](int64_t k) {
+					const Sub& sb = subs[(size_t)k];
+					const Piece& pc = sb.b->pieces[sb.piece];
+					const std::vector<TdRec>& v = *pc.recs;
+					for (int64_t r = sb.lo; r < sb.hi; r++) {
+						const TdRec& q = v[(size_t)r];
+						if (q.seq_off < 0) continue;
+						uint8_t* dst = sb.b->codes + sb.b->offs[pc.first + (r - pc.lo)];
+						const unsigned char* sq = (const unsigned char*)pc.blk->data + q.seq_off;
+						for (int32_t j = 0; j < q.seq_len; j++) dst[j] = code[sq[j]];
+					}
+				});
+				jobs.clear();
+				st.parse_s += now_s() - t_seg;                          // (time spent waiting for a free batch is not parsing)
+				for (Batch* b : full) if (!ready->push(b)) return false;
+				full.clear();
+				t_seg = now_s();
+				return true;
+			};
+			for (int k = 0; k < nchunk; k++) {
+				const std::vector<TdRec>& v = *recs[(size_t)k];
+				int64_t lo = 0;
+				while (lo < (int64_t)v.size()) {
+					if (!cur) {
+						if (!full.empty() && !flush()) return;
+						st.parse_s += now_s() - t_seg;
+						if (!free_list->pop(cur)) return;                  // aborted
+						t_seg = now_s();
+						cur->n = 0; cur->n_bases = 0; cur->pieces.clear(); cur->last = false; cur->ticket = 0;
+					}
+					const int64_t take = std::min<int64_t>((int64_t)v.size() - lo, (int64_t)o.batch_reads - cur->n);
+					Piece pc; pc.blk = blk; pc.recs = recs[(size_t)k]; pc.lo = lo; pc.hi = lo + take; pc.first = cur->n;
+					int64_t total = cur->n_bases;
+					for (int64_t r = lo; r < lo + take; r++) {
+						total += v[(size_t)r].seq_off >= 0 ? v[(size_t)r].seq_len : 0;
+						cur->offs[cur->n + (r - lo) + 1] = total;
+					}
+					cur->n += take; cur->n_bases = total;
+					cur->pieces.push_back(pc);
+					jobs.push_back(Job{ cur, cur->pieces.size() - 1 });
+					lo += take;
+					if (cur->n == o.batch_reads) { full.push_back(cur); cur = nullptr; }
+				}
+			}
+			if (!flush()) return;
+		}
+		if (cur && cur->n > 0) { cur->last = true; if (!ready->push(cur)) return; }
+		else if (cur) free_list->push(cur);
+		ready->close();
+	}
+
+	// ---- stage 3: format the records per output file and append them in input order ----
+	void consumer()
+	{
+		Batch* b = nullptr;
+		const int W = write_pool->size();
+		std::vector<OutBufs> bufs;
+		while (done->pop(b)) {
+			const double t0 = now_s();
+			if (!dry) {
+				struct Sub { size_t piece; int64_t lo, hi; };
+				std::vector<Sub> subs;
+				const int64_t step = std::max<int64_t>(4096, (b->n + W * 4 - 1) / (W * 4));
+				for (size_t p = 0; p < b->pieces.size(); p++)
+					for (int64_t a = b->pieces[p].lo; a < b->pieces[p].hi; a += step)
+						subs.push_back(Sub{ p, a, std::min<int64_t>(a + step, b->pieces[p].hi) });
+				if (bufs.size() < subs.size()) bufs.resize(subs.size());
+				for (size_t k = 0; k < subs.size(); k++) {
+					bufs[k].file.resize(fds.size());
+					for (auto& s : bufs[k].file) s.clear();
+				}
+				write_pool->run((int64_t)subs.size(), [&](int64_t k) {
+					const Sub& sb = subs[(size_t)k];
+					format_records(*b, b->pieces[sb.piece], sb.lo, sb.hi, num_alternatives, bufs[(size_t)k]);
+				});
+				// every sub-range's share of every file goes to its own place: the appends run in parallel and keep input order
+				struct Wr { size_t sub, file; int64_t at; };
+				std::vector<Wr> wr;
+				for (size_t f = 0; f < fds.size(); f++)
+					for (size_t k = 0; k < subs.size(); k++) {
+						const size_t sz = bufs[k].file[f].size();
+						if (!sz) continue;
+						wr.push_back(Wr{ k, f, file_off[f] });
+						file_off[f] += (int64_t)sz;
+						st.bytes_out += (int64_t)sz;
+					}
+				std::vector<int> wrc(wr.size(), 0);
+				write_pool->run((int64_t)wr.size(), [&](int64_t k) {
+					const Wr& w = wr[(size_t)k];
+					const std::string& s = bufs[w.sub].file[w.file];
+					size_t off = 0;
+					while (off < s.size()) {
+						const ssize_t r = pwrite(fds[w.file], s.data() + off, s.size() - off, (off_t)(w.at + (int64_t)off));
+						if (r < 0) { if (errno == EINTR) continue; wrc[(size_t)k] = errno ? errno : EIO; return; }
+						off += (size_t)r;
+					}
+				});
+				for (int e : wrc) if (e) { fail(std::string("td_stream_run: write failed: ") + strerror(e)); return; }
+			} else {
+				// parse-only run: a checksum over what would have gone to the device (lengths and codes, in order)
+				for (int64_t i = 0; i < b->n; i++) {
+					const int64_t l = b->offs[i + 1] - b->offs[i];
+					fnv = (fnv ^ (uint64_t)l) * 1099511628211ULL;
+					const uint8_t* s = b->codes + b->offs[i];
+					for (int64_t j = 0; j < l; j++) fnv = (fnv ^ s[j]) * 1099511628211ULL;
+				}
+			}
+			st.n_reads += b->n; st.n_batches++;
+			b->pieces.clear();                 // releases the blocks
+			st.write_s += now_s() - t0;
+			if (!free_list->push(b)) return;
+		}
+	}
+};
+
+} // namespace
+
+extern "C" int td_stream_run(td_ctx* ctx, const char* in_path, const td_arch* arch, const char* out_prefix,
+                             const td_stream_opts* opts, td_stream_stats* stats)
+{
+	if (!in_path) { td_io_set_error("td_stream_run: NULL input path"); return TD_FAIL; }
+	if (ctx && (!arch || !out_prefix)) { td_io_set_error("td_stream_run: a decoding run needs the architecture and an output prefix"); return TD_FAIL; }
+	Pipeline p;
+	p.ctx = ctx; p.arch = arch; p.dry = ctx == nullptr;
+	if (opts) p.o = *opts;
+	if (p.o.batch_reads <= 0) p.o.batch_reads = 1000001;          // param->num_query, barcode_hmm.c:172
+	if (p.o.block_bytes <= 0) p.o.block_bytes = (int64_t)64 << 20;
+	if (p.o.block_bytes < 4096) p.o.block_bytes = 4096;
+	int hw = (int)std::thread::hardware_concurrency();
+	if (hw < 1) hw = 1;
+	if (p.o.n_threads <= 0) p.o.n_threads = hw >= 16 ? 8 : (hw >= 4 ? hw / 2 : 1);
+	if (p.o.n_threads > 32) p.o.n_threads = 32;
+	int32_t depth = 3;
+	if (ctx) (void)td_get_option(ctx, "pipeline_depth", &depth);
+	const double t_start = now_s();
+	std::string err;
+	if (!p.src.open(in_path, p.o.block_bytes, err)) { td_io_set_error(err); return TD_FAIL; }
+	if (!p.dry) {
+		std::vector<std::string> names;
+		td_writer_file_names(out_prefix, arch, names, &p.num_alternatives);
+		for (auto& nm : names) {
+			const int fd = open(nm.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+			if (fd < 0) { for (int g : p.fds) close(g); td_io_set_error("td_stream_run: cannot create " + nm + ": " + strerror(errno)); return TD_FAIL; }
+			p.fds.push_back(fd);
+		}
+		p.file_off.assign(p.fds.size(), 0);
+	}
+	p.parse_pool.reset(new Pool(p.o.n_threads));
+	p.write_pool.reset(new Pool(p.o.n_threads));
+	// batches: `depth` on the device, one being filled, one being written, one spare on either side
+	const int n_batches = depth + 4;
+	p.ready.reset(new Queue<Batch*>((size_t)n_batches));
+	p.done.reset(new Queue<Batch*>((size_t)n_batches));
+	p.free_list.reset(new Queue<Batch*>((size_t)n_batches));
+	bool ok = true;
+	for (int k = 0; k < n_batches && ok; k++) {
+		Batch* b = p.new_batch();
+		if (!b) { ok = false; break; }
+		p.free_list->push(b);
+	}
+	int rc = TD_OK;
+	if (!ok) { p.fail("td_stream_run: page-locked memory exhausted"); rc = TD_FAIL; }
+	std::thread t_prod([&] { p.producer(); });
+	std::thread t_cons([&] { p.consumer(); });
+	// ---- stage 2, on the caller's thread (a context is driven from one thread): submit, keep `depth` in flight, wait in order ----
+	std::deque<Batch*> flying;
+	auto retire = [&]() -> bool {
+		Batch* b = flying.front();
+		flying.pop_front();
+		const double t0 = now_s();
+		if (ctx && td_wait(ctx, b->ticket) != TD_OK) { p.fail(std::string("td_stream_run: ") + td_last_error(ctx)); return false; }
+		p.st.decode_s += now_s() - t0;
+		return p.done->push(b);
+	};
+	Batch* b = nullptr;
+	while (rc == TD_OK && p.ready->pop(b)) {
+		if ((int)flying.size() >= depth && !retire()) break;
+		const double t0 = now_s();
+		if (ctx && td_submit(ctx, b->codes, 0, b->offs, b->n, TD_MODE_GET_LABEL, b->res, nullptr, b->seq_out, &b->ticket) != TD_OK) {
+			p.fail(std::string("td_stream_run: ") + td_last_error(ctx));
+			break;
+		}
+		p.st.decode_s += now_s() - t0;
+		flying.push_back(b);
+	}
+	while (!flying.empty() && !p.failed()) if (!retire()) break;
+	if (p.failed() && ctx) for (Batch* f : flying) (void)td_wait(ctx, f->ticket);   // nothing of ours may stay queued on the device
+	p.done->close();
+	t_prod.join();
+	t_cons.join();
+	for (int fd : p.fds) if (close(fd) != 0 && !p.failed()) p.fail(std::string("td_stream_run: close failed: ") + strerror(errno));
+	for (Batch* q : p.all) { buf_free(p.dry, q->codes); buf_free(p.dry, q->seq_out); buf_free(p.dry, q->offs); buf_free(p.dry, q->res); delete q; }
+	p.st.wall_s = now_s() - t_start;
+	p.st.codes_fnv = p.dry ? p.fnv : 0;
+	if (stats) *stats = p.st;
+	if (p.failed()) { td_io_set_error(p.err); return TD_FAIL; }
+	return rc;
+}

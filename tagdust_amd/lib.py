@@ -27,7 +27,7 @@ MULTI_ABI_SYMBOLS = ["td_shard_bounds", "td_count_outcomes", "td_multi_create", 
                      "td_multi_size", "td_multi_ctx", "td_multi_model_upload", "td_multi_set_params", "td_multi_set_window", "td_multi_set_artifacts",
                      "td_multi_decode", "td_multi_counts", "td_multi_counts_reset", "td_multi_uses_rccl", "td_bind_host_to_device"]
 IO_ABI_SYMBOLS = ["td_io_last_error", "td_reads_parse", "td_reads_free", "td_writer_open", "td_writer_write", "td_writer_close",
-                  "td_fasta_parse", "td_fasta_free"]
+                  "td_fasta_parse", "td_fasta_free", "td_stream_run"]
 MODEL_ABI_SYMBOLS = ["td_arch_parse", "td_arch_free", "td_sequence_stats", "td_sequence_stats_window", "td_model_build", "td_model_tables_free",
                      "td_calibration_emit", "td_calibration_select", "td_calibration_free", "td_estimate_threshold",
                      "td_compare_architectures", "td_simreads", "td_text_free"]
@@ -413,6 +413,40 @@ def write_demultiplexed(prefix, segments, reads, res, seq_out):
             raise TdError("td_writer_write/close failed")
     finally:
         lib.td_arch_free(arch)
+
+
+class _StreamOpts(C.Structure):
+    _fields_ = [("batch_reads", C.c_int32), ("n_threads", C.c_int32), ("block_bytes", C.c_int64)]
+
+
+class _StreamStats(C.Structure):
+    _fields_ = [("n_reads", C.c_int64), ("n_batches", C.c_int64), ("bytes_in", C.c_int64), ("bytes_out", C.c_int64),
+                ("wall_s", C.c_double), ("read_s", C.c_double), ("parse_s", C.c_double), ("decode_s", C.c_double),
+                ("write_s", C.c_double), ("codes_fnv", C.c_uint64)]
+
+
+def stream_run(ctx, in_path, segments=None, out_prefix=None, batch_reads=0, n_threads=0, block_bytes=0):
+    """td_stream_run: one input file through parse -> decode -> write as a pipeline; ctx None = parse-only run (no GPU).
+    Returns the statistics as a dict."""
+    lib = load_library()
+    lib.td_stream_run.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_char_p, C.POINTER(_StreamOpts), C.POINTER(_StreamStats)]
+    lib.td_io_last_error.restype = C.c_char_p
+    arch = C.c_void_p()
+    if segments is not None:
+        arr = (C.c_char_p * len(segments))(*[s.encode() for s in segments])
+        if lib.td_arch_parse(arr, len(segments), C.byref(arch)) != 0:
+            raise TdError("td_arch_parse failed for %r" % (segments,))
+    try:
+        o = _StreamOpts(int(batch_reads), int(n_threads), int(block_bytes))
+        st = _StreamStats()
+        rc = lib.td_stream_run(ctx.h if ctx is not None else None, os.fsencode(in_path), arch if segments is not None else None,
+                               os.fsencode(out_prefix) if out_prefix is not None else None, C.byref(o), C.byref(st))
+        if rc != 0:
+            raise TdError(lib.td_io_last_error().decode() or "td_stream_run failed")
+        return {k: getattr(st, k) for k, _ in _StreamStats._fields_}
+    finally:
+        if arch:
+            lib.td_arch_free(arch)
 
 
 def spec_source(md):

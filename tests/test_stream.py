@@ -1,0 +1,235 @@
+"""td_stream_run (include/tagdust_io.h): the reference's batch loop around run_pHMM for one file as a pipeline.  CPU part:
+the reader / parser stage alone (ctx NULL) must find the records td_reads_parse finds in the whole text -- the reference's
+line state machine, io.c:1697-1799 -- whatever the block size, and cut them into batches of exactly batch_reads records.
+GPU part: the files it writes equal those of the whole-text path and of the reference binary."""
+import glob
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_golden
+
+
+def _fnv(codes, offs):
+    h = 1469598103934665603
+    M = (1 << 64) - 1
+    for i in range(len(offs) - 1):
+        h = ((h ^ int(offs[i + 1] - offs[i])) * 1099511628211) & M
+        for c in codes[offs[i]:offs[i + 1]].tolist():
+            h = ((h ^ c) * 1099511628211) & M
+    return h
+
+
+def _ugly_fastq(n, seed, crlf=False):
+    """Records that exercise the state machine: ragged lengths, N / lower case / IUPAC letters / '.', names with blanks and a
+    tab (a control character ends the name), quality lines that start with '@' or '+'."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        L = int(rng.randint(1, 90))
+        s = "".join(rng.choice(list("ACGTNacgtRY."), L, p=[.22, .22, .22, .22, .03, .01, .01, .01, .01, .02, .02, .01]))
+        q = "".join(chr(c) for c in rng.randint(33, 74, L))
+        if i % 7 == 0:
+            q = "@" + q[1:]
+        if i % 11 == 0:
+            q = "+" + q[1:]
+        name = "r%d len=%d" % (i, L) + ("\textra" if i % 13 == 0 else "")
+        out.append("@%s\n%s\n+\n%s\n" % (name, s, q))
+    t = "".join(out)
+    return (t.replace("\n", "\r\n") if crlf else t).encode()
+
+
+@pytest.mark.parametrize("crlf", [False, True], ids=["lf", "crlf"])
+@pytest.mark.parametrize("block,batch,threads", [(4096, 777, 3), (50000, 1000, 1), (1 << 20, 100000, 4), (4096, 1, 2)])
+def test_parse_stage_equals_whole_text_parse(tmp_path, block, batch, threads, crlf):
+    from tagdust_amd import lib as tdlib
+    text = _ugly_fastq(5000 if batch > 1 else 300, 5, crlf)
+    path = str(tmp_path / "in.fq")
+    open(path, "wb").write(text)
+    pr = tdlib.ParsedReads(text, 1)
+    st = tdlib.stream_run(None, path, batch_reads=batch, n_threads=threads, block_bytes=block)
+    assert st["n_reads"] == pr.n and st["bytes_in"] == len(text)
+    assert st["n_batches"] == (pr.n + batch - 1) // batch
+    assert st["codes_fnv"] == _fnv(pr.codes, pr.offs)
+    pr.close()
+
+
+def test_compressed_and_fasta_input(tmp_path):
+    """.gz goes through zcat like the reference's io_handler (io.c:382-608), i.e. through the pipe reader with its carry-over
+    between blocks; FASTA records have no quality line."""
+    from tagdust_amd import lib as tdlib
+    text = _ugly_fastq(3000, 9)
+    pr = tdlib.ParsedReads(text, 1)
+    want = (pr.n, _fnv(pr.codes, pr.offs))
+    pr.close()
+    gz = str(tmp_path / "in.fq.gz")
+    with gzip.open(gz, "wb") as fh:
+        fh.write(text)
+    st = tdlib.stream_run(None, gz, batch_reads=500, n_threads=2, block_bytes=8192)
+    assert (st["n_reads"], st["codes_fnv"]) == want and st["n_batches"] == 6
+    fa = b"".join(b">s%d some text\n%s\n" % (i, b"ACGTNNAC"[: 1 + i % 8]) for i in range(1000))
+    path = str(tmp_path / "in.fa")
+    open(path, "wb").write(fa)
+    pr = tdlib.ParsedReads(fa, 1)
+    st = tdlib.stream_run(None, path, batch_reads=64, n_threads=2, block_bytes=4096)
+    assert st["n_reads"] == 1000 and st["codes_fnv"] == _fnv(pr.codes, pr.offs)
+    pr.close()
+
+
+def test_stream_errors_are_reported(tmp_path):
+    from tagdust_amd import lib as tdlib
+    from tagdust_amd import TdError
+    with pytest.raises(TdError, match="cannot find input file"):
+        tdlib.stream_run(None, str(tmp_path / "nope.fq"))
+    bad = str(tmp_path / "bad.fq")
+    open(bad, "wb").write(b"@a\nACGT\n+\nIIII\n@b\nACGTA\n+\nIII\n")
+    with pytest.raises(TdError, match="sequence has 5 characters, base qualities 3"):
+        tdlib.stream_run(None, bad)
+    sam = str(tmp_path / "x.sam")
+    open(sam, "wb").write(b"")
+    with pytest.raises(TdError, match="SAM/BAM"):
+        tdlib.stream_run(None, sam)
+    empty = str(tmp_path / "empty.fq")
+    open(empty, "wb").write(b"")
+    st = tdlib.stream_run(None, empty)
+    assert st["n_reads"] == 0 and st["n_batches"] == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+RBIN = os.path.join(REPO, "oracle", "_ref")
+
+
+def _files(d, prefix):
+    return {os.path.basename(p)[len(prefix):]: open(p, "rb").read() for p in sorted(glob.glob(os.path.join(d, prefix + "*.fq")))}
+
+
+def _segments(g):
+    a = str(g["cmdline"]).split()
+    return [a[i + 1] for i in range(len(a) - 1) if a[i].startswith("-") and a[i][1:].isdigit()]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,batch,block", [("c3_b6_s_r_p", 100, 4096), ("c2_indel_varlen", 64, 20000), ("b_r_s_r", 1000001, 0), ("umi_f_s_r", 37, 4096)])
+def test_stream_writes_the_files_of_the_whole_text_path(tmp_path, name, batch, block):
+    """Several small batches through the pipeline (reader, device, writer all busy at once) write byte for byte what
+    td_reads_parse -> td_batch_upload / td_run / td_batch_download -> td_writer_write write for the text at once -- which
+    tests/test_io.py and the drop-in tests tie to the reference binary's files."""
+    from test_dropin_gpu import _write_fastq
+    from tagdust_amd import TagdustHip
+    from tagdust_amd import lib as tdlib
+    g = load_golden(name)
+    fq = str(tmp_path / "in.fq")
+    _write_fastq(g, fq)
+    segs = _segments(g)
+    text = open(fq, "rb").read()
+    c = TagdustHip(0)
+    try:
+        c.upload_model(g)
+        c.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+        pr = tdlib.ParsedReads(text, 1)
+        c.upload_batch(pr.codes, pr.offs)
+        c.run()
+        res, _, seq_out = c.download(labels=False)
+        tdlib.write_demultiplexed(str(tmp_path / "whole"), segs, pr, res, seq_out)
+        pr.close()
+        c.counts_reset()
+        st = tdlib.stream_run(c, fq, segs, str(tmp_path / "stream"), batch_reads=batch, n_threads=3, block_bytes=block)
+        cnt = c.counts()
+    finally:
+        c.close()
+    n = int(g["n_reads"])
+    assert st["n_reads"] == n and st["n_batches"] == (n + batch - 1) // batch
+    assert int(cnt[:8].sum()) == int((g["lens"] > 0).sum())
+    a, b = _files(str(tmp_path), "whole"), _files(str(tmp_path), "stream")
+    assert a and set(a) == set(b)
+    for k in a:
+        assert a[k] == b[k], "output file *%s differs" % k
+    assert st["bytes_out"] == sum(len(v) for v in b.values())
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(RBIN, "tagdust_rtest")), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("threads", [1, 3])
+def test_stream_equals_the_reference_binary_with_artifact_filter(tmp_path, threads):
+    """The -DRTEST reference reads batches of 1000 records (barcode_hmm.c:165-175); with -ref the artifact filter's thread
+    ranges -- and with them which routine scores a read -- are taken per batch.  The fixture's reads, five times over (1100
+    reads: one full batch and a tail), through td_stream_run with batch_reads = 1000 must give the reference binary's files."""
+    from test_dropin_gpu import _write_fastq
+    from tagdust_amd import TagdustHip
+    from tagdust_amd import lib as tdlib
+    g = load_golden("artifacts_b_r")
+    one = str(tmp_path / "one.fq")
+    _write_fastq(g, one)
+    fq, fa = str(tmp_path / "in.fq"), str(tmp_path / "art.fa")
+    open(fq, "wb").write(open(one, "rb").read() * 5)
+    open(fa, "wb").write(bytes(g["art_fasta_text"]))
+    args = str(g["cmdline"]).split()
+    args[args.index("-ref") + 1] = fa
+    p = subprocess.run([os.path.join(RBIN, "tagdust_rtest")] + args + ["-t", str(threads), fq, "-o", "cpu"], cwd=str(tmp_path),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-1500:]
+    art = tdlib.parse_fasta(open(fa, "rb").read())
+    c = TagdustHip(0)
+    try:
+        c.set_artifacts(art[0], art[1], int(g["art_filter_error"]), threads)
+        c.upload_model(g)
+        c.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+        st = tdlib.stream_run(c, fq, _segments(g), str(tmp_path / "gpu"), batch_reads=1000, n_threads=2, block_bytes=30000)
+    finally:
+        c.close()
+    assert st["n_reads"] == 5 * int(g["n_reads"])
+    a, b = _files(str(tmp_path), "cpu"), _files(str(tmp_path), "gpu")
+    assert a and set(a) == set(b)
+    for k in a:
+        assert a[k] == b[k], "output file *%s differs" % k
+
+
+@pytest.mark.gpu
+def test_stream_at_full_batch_size(tmp_path):
+    """Three batches' worth of the bench workload (2.5 x 2^20 reads, 0.8 GB of FASTQ) with the reference's batch size: the
+    output of the concatenated file is the concatenation of the outputs of its parts (whole-text path, one part per call),
+    and the device counters add up."""
+    import bench
+    from tagdust_amd import TagdustHip
+    from tagdust_amd import lib as tdlib
+    bench.select_workload("c3")
+    model = bench.load_model()
+    segs = ["B:" + ",".join(bench.BARCODES), "S:" + bench.SPACER, "R:N", "P:" + bench.ADAPTER]
+    parts = [(1 << 20, 11), (1 << 20, 12), (1 << 19, 13)]
+    fq = str(tmp_path / "in.fq")
+    c = TagdustHip(0)
+    try:
+        c.upload_model(model)
+        c.set_params(float(model["threshold"]), 16, 100)
+        want = {}
+        with open(fq, "wb") as fh:
+            for k, (n, seed) in enumerate(parts):
+                part = str(tmp_path / ("part%d.fq" % k))
+                bench._write_fastq(part, bench.synth_batch(n, seed))
+                text = open(part, "rb").read()
+                fh.write(text)
+                pr = tdlib.ParsedReads(text, 8)
+                c.upload_batch(pr.codes, pr.offs)
+                c.run()
+                res, _, seq_out = c.download(labels=False)
+                tdlib.write_demultiplexed(str(tmp_path / ("p%d" % k)), segs, pr, res, seq_out)
+                pr.close()
+                for name, data in _files(str(tmp_path), "p%d" % k).items():
+                    want[name] = want.get(name, b"") + data
+                for f in glob.glob(str(tmp_path / ("p%d*" % k))) + [part]:
+                    os.remove(f)
+                del text
+        c.counts_reset()
+        st = tdlib.stream_run(c, fq, segs, str(tmp_path / "out"))
+        cnt = c.counts()
+    finally:
+        c.close()
+    total = sum(n for n, _ in parts)
+    assert st["n_reads"] == total and st["n_batches"] == 3 and int(cnt[:8].sum()) == total
+    got = _files(str(tmp_path), "out")
+    assert set(got) == set(want)
+    for k in want:
+        assert got[k] == want[k], "output file *%s differs" % k
