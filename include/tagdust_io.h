@@ -65,11 +65,13 @@ int  td_writer_close(td_writer* w);
  * steps of consecutive batches side by side: a reader/parser thread fills the next batch's page-locked buffers (records
  * found and base-coded by n_threads threads), the calling thread drives the device ("pipeline_depth" batches in flight), a
  * writer thread formats and appends finished batches (n_threads threads; every output file keeps input order).  A plain
- * file is mapped, not read.  Batches hold exactly batch_reads records like the reference's, whatever the block size.
+ * file is mapped, not read.  Batches hold exactly batch_reads records, whatever the block size.
  * The output files are those td_writer_open names, byte for byte what td_reads_parse / td_writer_write give for the whole
  * text at once.  ctx == NULL: a parse-only run (no GPU, nothing written) that fills stats, codes_fnv included. */
 typedef struct td_stream_opts {
-	int32_t batch_reads;   /* records per batch; 0 = 1 000 001 (param->num_query, src/barcode_hmm.c:172) */
+	int32_t batch_reads;   /* records per batch; 0 = 1 000 001 (param->num_query, src/barcode_hmm.c:172) when the context has a
+	                          -ref artifact filter -- its per-thread read ranges are taken over a batch, so the boundaries are part
+	                          of the result -- and 2^18 otherwise (results do not depend on the batching then) */
 	int32_t n_threads;     /* host threads of the parse stage and of the write stage, each; 0 = pick (<= 8) */
 	int64_t block_bytes;   /* bytes of input taken at a time; 0 = 64 MiB */
 } td_stream_opts;
@@ -82,6 +84,9 @@ typedef struct td_stream_stats {
 	double  write_s;       /* write stage busy: formatting + appends */
 	uint64_t codes_fnv;    /* parse-only runs: FNV-1a over (read length, base codes) of all reads in order; else 0 */
 } td_stream_stats;
+/* ";RQ:%0.2f" of print_all() (io.c:963-992) without printf: the characters "%0.2f" gives for q, into buf[48]; returns their
+ * number.  Exposed so that tests can hold it against printf. */
+int td_format_q(float q, char* buf);
 int td_stream_run(td_ctx* ctx, const char* in_path, const td_arch* arch, const char* out_prefix,
                   const td_stream_opts* opts, td_stream_stats* stats);
 

@@ -622,6 +622,7 @@ extern "C" int td_get_option(td_ctx* c, const char* name, int32_t* value)
 	if (!strcmp(name, "spec_lsum_clamped")) { *value = c->spec_ready && !c->spec_oob; return TD_OK; }
 	if (!strcmp(name, "pipeline_depth")) { *value = c->pipeline_depth; return TD_OK; }
 	if (!strcmp(name, "host_threads")) { *value = c->host_threads; return TD_OK; }
+	if (!strcmp(name, "artifacts_active")) { *value = c->art_n > 0; return TD_OK; }
 	if (!strcmp(name, "overlap_decode")) { *value = c->overlap; return TD_OK; }
 	// which fast paths the model / the last batch actually got (read-only)
 	if (!strcmp(name, "prune_active")) {

@@ -19,7 +19,10 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <math.h>
+
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -276,10 +279,11 @@ struct Batch {
 void* buf_alloc(bool dry, size_t bytes) { return dry ? malloc(bytes ? bytes : 1) : td_host_alloc(bytes); }
 void buf_free(bool dry, void* p) { if (dry) free(p); else td_host_free(p); }
 
-bool grow_buf(bool dry, uint8_t** p, size_t* cap, size_t need, size_t keep)
+bool grow_buf(bool dry, uint8_t** p, size_t* cap, size_t need, size_t keep, size_t hint)
 {
 	if (*cap >= need) return true;
 	size_t want = need + need / 4 + 4096;
+	if (want < hint) want = hint;          // what a whole batch is expected to need: allocated once, reused by later batches
 	uint8_t* q = (uint8_t*)buf_alloc(dry, want);
 	if (!q) return false;
 	if (*p && keep) memcpy(q, *p, keep);
@@ -288,17 +292,68 @@ bool grow_buf(bool dry, uint8_t** p, size_t* cap, size_t need, size_t keep)
 	return true;
 }
 
+// a growing byte buffer without the zero-fill of std::string::resize
+struct Bytes {
+	char* p = nullptr;
+	size_t n = 0, cap = 0;
+	Bytes() = default;
+	Bytes(const Bytes&) = delete;
+	Bytes& operator=(const Bytes&) = delete;
+	Bytes(Bytes&& o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+	~Bytes() { free(p); }
+	char* room(size_t more)
+	{
+		if (n + more > cap) {
+			size_t c = cap ? cap * 2 : (size_t)1 << 16;
+			while (c < n + more) c *= 2;
+			p = (char*)realloc(p, c);
+			cap = c;
+		}
+		return p + n;
+	}
+};
+
+// "%d"
+inline int put_int(char* w, int v)
+{
+	char tmp[16];
+	int k = 0;
+	unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+	do { tmp[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+	int o = 0;
+	if (v < 0) w[o++] = '-';
+	while (k) w[o++] = tmp[--k];
+	return o;
+}
+
+// "%0.2f" of a float, digit for digit what printf prints: the float times 100 is exact in double (24 x 7 significant bits),
+// nearbyint rounds it half-to-even like printf rounds the exact decimal expansion; anything unusual goes to snprintf
+inline int put_q(char* w, float q)
+{
+	const double x = (double)q * 100.0;
+	if (!(x >= 0.0 && x < 1.0e15) || (x == 0.0 && std::signbit(q))) return snprintf(w, 48, "%0.2f", (double)q);   // (at most 42 characters)
+	unsigned long long u = (unsigned long long)nearbyint(x);
+	char tmp[24];
+	int k = 0;
+	tmp[k++] = (char)('0' + u % 10); u /= 10;
+	tmp[k++] = (char)('0' + u % 10); u /= 10;
+	tmp[k++] = '.';
+	do { tmp[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+	int o = 0;
+	while (k) w[o++] = tmp[--k];
+	return o;
+}
+
 // formats the records of one piece sub-range into one buffer per output file (print_all(), io.c:917-1001)
-struct OutBufs { std::vector<std::string> file; };
+struct OutBufs { std::vector<Bytes> file; };
 
 void format_records(const Batch& b, const Piece& pc, int64_t lo, int64_t hi, int num_alternatives, OutBufs& out)
 {
 	static const char alphabet[] = "ACGTNN";
 	const char* text = pc.blk->data;
 	const std::vector<TdRec>& recs = *pc.recs;
-	char head[64];
+	char head[96];
 	const size_t n_files = out.file.size();
-	std::string seq, qual;
 	for (int64_t r = lo; r < hi; r++) {
 		const TdRec& rec = recs[(size_t)r];
 		const int64_t i = pc.first + (r - pc.lo);             // index in the batch
@@ -316,18 +371,19 @@ void format_records(const Batch& b, const Piece& pc, int64_t lo, int64_t hi, int
 			const int64_t g0 = g;
 			while (g < len && s[g] < 5) g++;
 			if (g == g0) break;
-			if (f < n_files) {                                 // io.c:955-975
-				std::string& o = out.file[f];
+			if (f < n_files) {                                 // io.c:955-975: "@<name>[;FP:%d];RQ:%0.2f"
 				if (head_len < 0) {
 					int k = 0;
-					if (rr.fingerprint != -1) k = snprintf(head, sizeof head, ";FP:%d", rr.fingerprint);
-					k += snprintf(head + k, sizeof head - (size_t)k, ";RQ:%0.2f\n", (double)rr.mapq);
+					if (rr.fingerprint != -1) { memcpy(head, ";FP:", 4); k = 4 + put_int(head + 4, rr.fingerprint); }
+					memcpy(head + k, ";RQ:", 4); k += 4;
+					k += put_q(head + k, rr.mapq);
+					head[k++] = '\n';
 					head_len = k;
 				}
 				const size_t run = (size_t)(g - g0);
-				const size_t at = o.size();
-				o.resize(at + 1 + (size_t)rec.name_len + (size_t)head_len + run + 3 + run + 1);
-				char* w = &o[at];
+				Bytes& o = out.file[f];
+				const size_t total = 1 + (size_t)rec.name_len + (size_t)head_len + run + 3 + run + 1;
+				char* w = o.room(total);
 				*w++ = '@';
 				memcpy(w, text + rec.name_off, (size_t)rec.name_len); w += rec.name_len;
 				memcpy(w, head, (size_t)head_len); w += head_len;
@@ -337,6 +393,7 @@ void format_records(const Batch& b, const Piece& pc, int64_t lo, int64_t hi, int
 				if (q) memcpy(w, q + g0, run); else memset(w, '.', run);
 				w += run;
 				*w++ = '\n';
+				o.n += total;
 			}
 			f += (size_t)num_alternatives;
 		}
@@ -359,6 +416,11 @@ struct Pipeline {
 	int num_alternatives = 2;
 	bool dry = false;
 	uint64_t fnv = 1469598103934665603ULL;
+	double dbg_pass1 = 0, dbg_grow = 0, dbg_encode = 0, dbg_format = 0, dbg_pwrite = 0;
+	size_t batch_hint = 0;
+	std::mutex all_mu;
+	std::condition_variable hint_cv;
+	bool hint_ready = false, stop_alloc = false;
 
 	void fail(const std::string& m)
 	{
@@ -374,8 +436,27 @@ struct Pipeline {
 		b->res = (td_read_result*)buf_alloc(dry, sizeof(td_read_result) * (size_t)o.batch_reads);
 		if (!b->offs || !b->res) { buf_free(dry, b->offs); buf_free(dry, b->res); delete b; return nullptr; }
 		b->offs[0] = 0;
-		all.push_back(b);
+		{ std::lock_guard<std::mutex> lk(all_mu); all.push_back(b); }
 		return b;
+	}
+
+	// The batch buffers are page-locked, and page-locking runs at about 1 GB/s: the pipeline starts with two batches and this
+	// thread adds the others, sized for a whole batch (known after the first block), while the first ones are already at work.
+	void allocator(int n_more)
+	{
+		size_t hint = 0;
+		{
+			std::unique_lock<std::mutex> lk(all_mu);
+			hint_cv.wait(lk, [&] { return hint_ready || stop_alloc; });
+			if (stop_alloc) return;
+			hint = batch_hint;
+		}
+		for (int k = 0; k < n_more; k++) {
+			{ std::lock_guard<std::mutex> lk(all_mu); if (stop_alloc) return; }
+			Batch* b = new_batch();
+			if (!b || !grow_buf(dry, &b->codes, &b->cap_codes, hint, 0, hint) || !grow_buf(dry, &b->seq_out, &b->cap_seq, hint, 0, hint)) return;   // (the pipeline runs with what it has)
+			if (!free_list->push(b)) return;
+		}
 	}
 
 	// ---- stage 1: read / map a block, find its records, hand them out to batches, base-code them ----
@@ -410,6 +491,7 @@ struct Pipeline {
 				for (size_t i = 0; i < v.size(); i++)
 					if (v[i].qual_off >= 0 && v[i].qual_len != (v[i].seq_off >= 0 ? v[i].seq_len : 0)) { bad[(size_t)k] = (int64_t)i; break; }
 			});
+			dbg_pass1 += now_s() - t0;
 			for (int k = 0; k < nchunk; k++)
 				if (bad[(size_t)k] >= 0) {
 					const TdRec& q = (*recs[(size_t)k])[(size_t)bad[(size_t)k]];
@@ -419,6 +501,17 @@ struct Pipeline {
 					fail(msg);
 					return;
 				}
+			{   // bases a full batch of reads like this block's will hold (+6 %)
+				int64_t nrec = 0, nb = 0;
+				for (auto& r : recs) { nrec += (int64_t)r->size(); for (const TdRec& q : *r) nb += q.seq_off >= 0 ? q.seq_len : 0; }
+				if (nrec > 0) {
+					const size_t h = (size_t)((double)nb / (double)nrec * (double)o.batch_reads * 1.06) + 4096;
+					std::lock_guard<std::mutex> lk(all_mu);
+					if (h > batch_hint) batch_hint = h;
+					hint_ready = true;
+					hint_cv.notify_all();
+				}
+			}
 			// hand the records out to batches of exactly batch_reads, in order (offsets by a running sum); the pieces handed out
 			// are base-coded (init_nuc_code) in parallel and full batches passed on whenever two are waiting, and before this
 			// thread might have to wait for a free batch
@@ -428,6 +521,7 @@ struct Pipeline {
 			const uint8_t* code = td_nuc_code_ptr;
 			double t_seg = t0;
 			auto flush = [&]() -> bool {
+				const double tf0 = now_s();
 				std::vector<Batch*> touched = full;
 				if (cur) touched.push_back(cur);
 				for (Batch* b : touched) {
@@ -437,9 +531,11 @@ struct Pipeline {
 					size_t keep = 0;
 					for (const Job& j : jobs) if (j.b == b) { keep = (size_t)b->offs[b->pieces[j.piece].first]; mine = true; break; }
 					if (!mine) continue;
-					if (!grow_buf(dry, &b->codes, &b->cap_codes, (size_t)b->n_bases + 1, keep) ||
-					    !grow_buf(dry, &b->seq_out, &b->cap_seq, (size_t)b->n_bases + 1, 0)) { fail("td_stream_run: page-locked memory exhausted"); return false; }
+					if (!grow_buf(dry, &b->codes, &b->cap_codes, (size_t)b->n_bases + 1, keep, batch_hint) ||
+					    !grow_buf(dry, &b->seq_out, &b->cap_seq, (size_t)b->n_bases + 1, 0, batch_hint)) { fail("td_stream_run: page-locked memory exhausted"); return false; }
 				}
+				dbg_grow += now_s() - tf0;
+				const double tf1 = now_s();
 				struct Sub { Batch* b; size_t piece; int64_t lo, hi; };
 				std::vector<Sub> subs;
 				for (const Job& j : jobs) {
@@ -459,6 +555,7 @@ struct Pipeline {
 					}
 				});
 				jobs.clear();
+				dbg_encode += now_s() - tf1;
 				st.parse_s += now_s() - t_seg;                          // (time spent waiting for a free batch is not parsing)
 				for (Batch* b : full) if (!ready->push(b)) return false;
 				full.clear();
@@ -492,6 +589,7 @@ struct Pipeline {
 			}
 			if (!flush()) return;
 		}
+		if (getenv("TD_STREAM_DEBUG")) fprintf(stderr, "td_stream: records %.3f s, buffers %.3f s, base codes %.3f s (parse stage %.3f s)\n", dbg_pass1, dbg_grow, dbg_encode, st.parse_s);
 		if (cur && cur->n > 0) { cur->last = true; if (!ready->push(cur)) return; }
 		else if (cur) free_list->push(cur);
 		ready->close();
@@ -514,35 +612,59 @@ struct Pipeline {
 						subs.push_back(Sub{ p, a, std::min<int64_t>(a + step, b->pieces[p].hi) });
 				if (bufs.size() < subs.size()) bufs.resize(subs.size());
 				for (size_t k = 0; k < subs.size(); k++) {
-					bufs[k].file.resize(fds.size());
-					for (auto& s : bufs[k].file) s.clear();
+					if (bufs[k].file.size() != fds.size()) bufs[k].file.resize(fds.size());
+					for (auto& s : bufs[k].file) s.n = 0;
 				}
 				write_pool->run((int64_t)subs.size(), [&](int64_t k) {
 					const Sub& sb = subs[(size_t)k];
 					format_records(*b, b->pieces[sb.piece], sb.lo, sb.hi, num_alternatives, bufs[(size_t)k]);
 				});
-				// every sub-range's share of every file goes to its own place: the appends run in parallel and keep input order
-				struct Wr { size_t sub, file; int64_t at; };
+				dbg_format += now_s() - t0;
+				// Appends.  Buffered writes to one file serialise on its inode lock (8 threads on one file: 8 GB/s; one thread on each of
+				// nine files: 56 GB/s, tools/ubench/file_write.cpp), so a file gets one task that appends its share of every sub-range
+				// in order -- or a few tasks over runs of sub-ranges when it takes most of the bytes (no barcode segment: two files)
+				struct Wr { size_t file, k0, k1; int64_t at; };
 				std::vector<Wr> wr;
-				for (size_t f = 0; f < fds.size(); f++)
+				int64_t total_bytes = 0;
+				std::vector<int64_t> per_file(fds.size(), 0);
+				for (size_t f = 0; f < fds.size(); f++) {
+					for (size_t k = 0; k < subs.size(); k++) per_file[f] += (int64_t)bufs[k].file[f].n;
+					total_bytes += per_file[f];
+				}
+				for (size_t f = 0; f < fds.size(); f++) {
+					if (!per_file[f]) continue;
+					int parts = (int)((double)per_file[f] / (double)total_bytes * (double)W + 0.5);
+					if (parts > 4) parts = 4;
+					if (parts < 1) parts = 1;
+					const int64_t target = (per_file[f] + parts - 1) / parts;
+					int64_t at = file_off[f], acc = 0;
+					size_t k0 = 0;
 					for (size_t k = 0; k < subs.size(); k++) {
-						const size_t sz = bufs[k].file[f].size();
-						if (!sz) continue;
-						wr.push_back(Wr{ k, f, file_off[f] });
-						file_off[f] += (int64_t)sz;
-						st.bytes_out += (int64_t)sz;
+						acc += (int64_t)bufs[k].file[f].n;
+						if (acc >= target || k + 1 == subs.size()) {
+							if (acc > 0) wr.push_back(Wr{ f, k0, k + 1, at });
+							at += acc; acc = 0; k0 = k + 1;
+						}
 					}
+					file_off[f] += per_file[f];
+					st.bytes_out += per_file[f];
+				}
 				std::vector<int> wrc(wr.size(), 0);
-				write_pool->run((int64_t)wr.size(), [&](int64_t k) {
-					const Wr& w = wr[(size_t)k];
-					const std::string& s = bufs[w.sub].file[w.file];
-					size_t off = 0;
-					while (off < s.size()) {
-						const ssize_t r = pwrite(fds[w.file], s.data() + off, s.size() - off, (off_t)(w.at + (int64_t)off));
-						if (r < 0) { if (errno == EINTR) continue; wrc[(size_t)k] = errno ? errno : EIO; return; }
-						off += (size_t)r;
+				write_pool->run((int64_t)wr.size(), [&](int64_t t) {
+					const Wr& w = wr[(size_t)t];
+					int64_t at = w.at;
+					for (size_t k = w.k0; k < w.k1; k++) {
+						const Bytes& s = bufs[k].file[w.file];
+						size_t off = 0;
+						while (off < s.n) {
+							const ssize_t r = pwrite(fds[w.file], s.p + off, s.n - off, (off_t)(at + (int64_t)off));
+							if (r < 0) { if (errno == EINTR) continue; wrc[(size_t)t] = errno ? errno : EIO; return; }
+							off += (size_t)r;
+						}
+						at += (int64_t)s.n;
 					}
 				});
+				dbg_pwrite = dbg_pwrite + (now_s() - t0);
 				for (int e : wrc) if (e) { fail(std::string("td_stream_run: write failed: ") + strerror(e)); return; }
 			} else {
 				// parse-only run: a checksum over what would have gone to the device (lengths and codes, in order)
@@ -558,10 +680,14 @@ struct Pipeline {
 			st.write_s += now_s() - t0;
 			if (!free_list->push(b)) return;
 		}
+		if (getenv("TD_STREAM_DEBUG")) fprintf(stderr, "td_stream: formatting %.3f s, appends %.3f s (write stage %.3f s)\n", dbg_format, dbg_pwrite - dbg_format, st.write_s);
 	}
 };
 
 } // namespace
+
+// the writer's "%0.2f" (tests compare it with printf digit for digit); returns the number of characters written to buf[48]
+extern "C" int td_format_q(float q, char* buf) { return put_q(buf, q); }
 
 extern "C" int td_stream_run(td_ctx* ctx, const char* in_path, const td_arch* arch, const char* out_prefix,
                              const td_stream_opts* opts, td_stream_stats* stats)
@@ -571,7 +697,15 @@ extern "C" int td_stream_run(td_ctx* ctx, const char* in_path, const td_arch* ar
 	Pipeline p;
 	p.ctx = ctx; p.arch = arch; p.dry = ctx == nullptr;
 	if (opts) p.o = *opts;
-	if (p.o.batch_reads <= 0) p.o.batch_reads = 1000001;          // param->num_query, barcode_hmm.c:172
+	if (p.o.batch_reads <= 0) {
+		// The reference reads 1 000 001 records at a time (param->num_query, barcode_hmm.c:172).  Per-read results do not depend on
+		// how a file is cut into batches -- except through the -ref artifact filter, whose per-thread read ranges are taken over a
+		// batch: with a filter set the batches are the reference's, without one they are 2^18 reads (one tile per wave slot of
+		// the device; a quarter of the page-locked memory and a pipeline that fills four times sooner).
+		int32_t art = 0;
+		if (ctx) (void)td_get_option(ctx, "artifacts_active", &art);
+		p.o.batch_reads = (!ctx || art) ? 1000001 : (1 << 18);
+	}
 	if (p.o.block_bytes <= 0) p.o.block_bytes = (int64_t)64 << 20;
 	if (p.o.block_bytes < 4096) p.o.block_bytes = 4096;
 	int hw = (int)std::thread::hardware_concurrency();
@@ -601,13 +735,14 @@ extern "C" int td_stream_run(td_ctx* ctx, const char* in_path, const td_arch* ar
 	p.done.reset(new Queue<Batch*>((size_t)n_batches));
 	p.free_list.reset(new Queue<Batch*>((size_t)n_batches));
 	bool ok = true;
-	for (int k = 0; k < n_batches && ok; k++) {
+	for (int k = 0; k < 2 && ok; k++) {
 		Batch* b = p.new_batch();
 		if (!b) { ok = false; break; }
 		p.free_list->push(b);
 	}
 	int rc = TD_OK;
 	if (!ok) { p.fail("td_stream_run: page-locked memory exhausted"); rc = TD_FAIL; }
+	std::thread t_alloc([&] { p.allocator(n_batches - 2); });
 	std::thread t_prod([&] { p.producer(); });
 	std::thread t_cons([&] { p.consumer(); });
 	// ---- stage 2, on the caller's thread (a context is driven from one thread): submit, keep `depth` in flight, wait in order ----
@@ -636,6 +771,10 @@ extern "C" int td_stream_run(td_ctx* ctx, const char* in_path, const td_arch* ar
 	p.done->close();
 	t_prod.join();
 	t_cons.join();
+	{ std::lock_guard<std::mutex> lk(p.all_mu); p.stop_alloc = true; }
+	p.hint_cv.notify_all();
+	p.free_list->abort();          // (an allocator waiting to hand over a batch)
+	t_alloc.join();
 	for (int fd : p.fds) if (close(fd) != 0 && !p.failed()) p.fail(std::string("td_stream_run: close failed: ") + strerror(errno));
 	for (Batch* q : p.all) { buf_free(p.dry, q->codes); buf_free(p.dry, q->seq_out); buf_free(p.dry, q->offs); buf_free(p.dry, q->res); delete q; }
 	p.st.wall_s = now_s() - t_start;

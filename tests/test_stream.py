@@ -98,6 +98,28 @@ def test_stream_errors_are_reported(tmp_path):
     assert st["n_reads"] == 0 and st["n_batches"] == 0
 
 
+def test_rq_formatting_equals_printf():
+    """The writer formats ";RQ:%0.2f" itself (float x 100 is exact in double, nearbyint rounds half to even like printf rounds
+    the exact expansion).  Against C's printf (ctypes) on random floats of every magnitude a Q takes, on every tie k/200 +- 1 ulp,
+    and on the values that must fall back to printf (negative, -0, inf, nan, huge)."""
+    import ctypes as C
+    from tagdust_amd import lib as tdlib
+    lib = tdlib.load_library()
+    lib.td_format_q.argtypes = [C.c_float, C.c_char_p]
+    libc = C.CDLL(None)
+    libc.snprintf.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_double]
+    rng = np.random.default_rng(3)
+    vals = [rng.random(150000, dtype=np.float32) * np.float32(s) for s in (1, 10, 100, 1000, 1e6)]
+    ties = (np.arange(0, 40000, dtype=np.float64) / 200.0).astype(np.float32)
+    vals += [ties, np.nextafter(ties, np.float32(1e9)), np.nextafter(ties, np.float32(-1))]
+    vals.append(np.array([0.0, -0.0, -0.004, -1.5, np.inf, -np.inf, np.nan, 3e38, 1e15, 99999.995, 0.005, 0.015, 0.025, 1.005], np.float32))
+    a, b = C.create_string_buffer(64), C.create_string_buffer(400)
+    for v in np.concatenate(vals).tolist():
+        n = lib.td_format_q(v, a)
+        libc.snprintf(b, 400, b"%0.2f", float(np.float32(v)))
+        assert a.raw[:n] == b.value, (v, a.raw[:n], b.value)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 RBIN = os.path.join(REPO, "oracle", "_ref")
 
@@ -172,11 +194,19 @@ def test_stream_equals_the_reference_binary_with_artifact_filter(tmp_path, threa
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert p.returncode == 0, p.stdout.decode(errors="replace")[-1500:]
     art = tdlib.parse_fasta(open(fa, "rb").read())
+    segs = _segments(g)
+    # sequence statistics, model and calibrated threshold come from the file's first batch (io.c:52-300 reads num_query = 1000
+    # records in the -DRTEST build), like the reference's own prologue
+    head = tdlib.ParsedReads(open(fq, "rb").read(), 1)
+    hc, ho = head.codes[:head.offs[1000]].copy(), head.offs[:1001].copy()
+    head.close()
     c = TagdustHip(0)
     try:
+        thr = tdlib.estimate_threshold(c, segs, hc, ho, float(g["d"]), seed=42, n_reads=4000, rng=1)
+        model, _ = tdlib.build_model(segs, hc, ho, 0.05, float(g["d"]))
         c.set_artifacts(art[0], art[1], int(g["art_filter_error"]), threads)
-        c.upload_model(g)
-        c.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+        c.upload_model(model)
+        c.set_params(thr, int(g["minlen"]), int(g["dust"]))
         st = tdlib.stream_run(c, fq, _segments(g), str(tmp_path / "gpu"), batch_reads=1000, n_threads=2, block_bytes=30000)
     finally:
         c.close()
@@ -223,7 +253,7 @@ def test_stream_at_full_batch_size(tmp_path):
                     os.remove(f)
                 del text
         c.counts_reset()
-        st = tdlib.stream_run(c, fq, segs, str(tmp_path / "out"))
+        st = tdlib.stream_run(c, fq, segs, str(tmp_path / "out"), batch_reads=1000001)
         cnt = c.counts()
     finally:
         c.close()
