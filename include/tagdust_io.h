@@ -89,6 +89,9 @@ typedef struct td_stream_stats {
 int td_format_q(float q, char* buf);
 int td_stream_run(td_ctx* ctx, const char* in_path, const td_arch* arch, const char* out_prefix,
                   const td_stream_opts* opts, td_stream_stats* stats);
+/* td_stream_run keeps the page-locked batch buffers of its last run (at most 1 GiB) for the next run of the process --
+ * page-locking runs at about 1 GB/s, most of what a short file costs; this frees them. */
+void td_stream_release(void);
 
 #ifdef __cplusplus
 }

@@ -273,7 +273,19 @@ struct Batch {
 	std::vector<Piece> pieces;
 	int64_t ticket = 0;
 	bool last = false;
+	int64_t cap_reads = 0;      // offs / res hold this many reads
 };
+
+// Page-locked batch buffers outlive a run: page-locking runs at about 1 GB/s, which is most of what a short file costs.  The
+// buffers of the last run (up to 1 GiB) wait here for the next one of the same process; td_stream_release frees them.
+std::mutex g_cache_mu;
+std::vector<Batch*> g_cache;
+const size_t kCacheBytes = (size_t)1 << 30;
+
+size_t batch_bytes(const Batch* b)
+{
+	return b->cap_codes + b->cap_seq + (size_t)b->cap_reads * (sizeof(int64_t) + sizeof(td_read_result));
+}
 
 // batch buffers: page-locked for the device; plain memory for a parse-only run (no GPU runtime needed then)
 void* buf_alloc(bool dry, size_t bytes) { return dry ? malloc(bytes ? bytes : 1) : td_host_alloc(bytes); }
@@ -431,7 +443,20 @@ struct Pipeline {
 
 	Batch* new_batch()
 	{
+		if (!dry) {   // one the last run left behind?
+			std::lock_guard<std::mutex> lk(g_cache_mu);
+			for (size_t k = 0; k < g_cache.size(); k++)
+				if (g_cache[k]->cap_reads >= o.batch_reads) {
+					Batch* b = g_cache[k];
+					g_cache.erase(g_cache.begin() + (long)k);
+					b->offs[0] = 0;
+					std::lock_guard<std::mutex> lk2(all_mu);
+					all.push_back(b);
+					return b;
+				}
+		}
 		Batch* b = new Batch();
+		b->cap_reads = o.batch_reads;
 		b->offs = (int64_t*)buf_alloc(dry, sizeof(int64_t) * ((size_t)o.batch_reads + 1));
 		b->res = (td_read_result*)buf_alloc(dry, sizeof(td_read_result) * (size_t)o.batch_reads);
 		if (!b->offs || !b->res) { buf_free(dry, b->offs); buf_free(dry, b->res); delete b; return nullptr; }
@@ -686,6 +711,13 @@ struct Pipeline {
 
 } // namespace
 
+extern "C" void td_stream_release(void)
+{
+	std::lock_guard<std::mutex> lk(g_cache_mu);
+	for (Batch* q : g_cache) { td_host_free(q->codes); td_host_free(q->seq_out); td_host_free(q->offs); td_host_free(q->res); delete q; }
+	g_cache.clear();
+}
+
 // the writer's "%0.2f" (tests compare it with printf digit for digit); returns the number of characters written to buf[48]
 extern "C" int td_format_q(float q, char* buf) { return put_q(buf, q); }
 
@@ -776,7 +808,21 @@ extern "C" int td_stream_run(td_ctx* ctx, const char* in_path, const td_arch* ar
 	p.free_list->abort();          // (an allocator waiting to hand over a batch)
 	t_alloc.join();
 	for (int fd : p.fds) if (close(fd) != 0 && !p.failed()) p.fail(std::string("td_stream_run: close failed: ") + strerror(errno));
-	for (Batch* q : p.all) { buf_free(p.dry, q->codes); buf_free(p.dry, q->seq_out); buf_free(p.dry, q->offs); buf_free(p.dry, q->res); delete q; }
+	{
+		std::lock_guard<std::mutex> lk(g_cache_mu);
+		size_t held = 0;
+		for (const Batch* q : g_cache) held += batch_bytes(q);
+		for (Batch* q : p.all) {
+			if (!p.dry && !p.failed() && q->codes && held + batch_bytes(q) <= kCacheBytes) {
+				q->pieces.clear(); q->n = 0; q->n_bases = 0; q->ticket = 0;
+				held += batch_bytes(q);
+				g_cache.push_back(q);
+				continue;
+			}
+			buf_free(p.dry, q->codes); buf_free(p.dry, q->seq_out); buf_free(p.dry, q->offs); buf_free(p.dry, q->res);
+			delete q;
+		}
+	}
 	p.st.wall_s = now_s() - t_start;
 	p.st.codes_fnv = p.dry ? p.fnv : 0;
 	if (stats) *stats = p.st;

@@ -27,7 +27,7 @@ MULTI_ABI_SYMBOLS = ["td_shard_bounds", "td_count_outcomes", "td_multi_create", 
                      "td_multi_size", "td_multi_ctx", "td_multi_model_upload", "td_multi_set_params", "td_multi_set_window", "td_multi_set_artifacts",
                      "td_multi_decode", "td_multi_counts", "td_multi_counts_reset", "td_multi_uses_rccl", "td_bind_host_to_device"]
 IO_ABI_SYMBOLS = ["td_io_last_error", "td_reads_parse", "td_reads_free", "td_writer_open", "td_writer_write", "td_writer_close",
-                  "td_fasta_parse", "td_fasta_free", "td_stream_run", "td_format_q"]
+                  "td_fasta_parse", "td_fasta_free", "td_stream_run", "td_stream_release", "td_format_q"]
 MODEL_ABI_SYMBOLS = ["td_arch_parse", "td_arch_free", "td_sequence_stats", "td_sequence_stats_window", "td_model_build", "td_model_tables_free",
                      "td_calibration_emit", "td_calibration_select", "td_calibration_free", "td_estimate_threshold",
                      "td_compare_architectures", "td_simreads", "td_text_free"]

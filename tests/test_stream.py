@@ -177,7 +177,7 @@ def test_stream_writes_the_files_of_the_whole_text_path(tmp_path, name, batch, b
 @pytest.mark.parametrize("threads", [1, 3])
 def test_stream_equals_the_reference_binary_with_artifact_filter(tmp_path, threads):
     """The -DRTEST reference reads batches of 1000 records (barcode_hmm.c:165-175); with -ref the artifact filter's thread
-    ranges -- and with them which routine scores a read -- are taken per batch.  The fixture's reads, five times over (1100
+    ranges -- and with them which routine scores a read -- are taken per batch.  The fixture's reads, five times over (1015
     reads: one full batch and a tail), through td_stream_run with batch_reads = 1000 must give the reference binary's files."""
     from test_dropin_gpu import _write_fastq
     from tagdust_amd import TagdustHip
@@ -195,10 +195,10 @@ def test_stream_equals_the_reference_binary_with_artifact_filter(tmp_path, threa
     assert p.returncode == 0, p.stdout.decode(errors="replace")[-1500:]
     art = tdlib.parse_fasta(open(fa, "rb").read())
     segs = _segments(g)
-    # sequence statistics, model and calibrated threshold come from the file's first batch (io.c:52-300 reads num_query = 1000
-    # records in the -DRTEST build), like the reference's own prologue
+    # sequence statistics, model and calibrated threshold like the reference's own prologue: get_sequence_stats() reads batches
+    # until it has seen more than 1 000 000 reads (io.c:125-188) -- this file is shorter, so all of it
     head = tdlib.ParsedReads(open(fq, "rb").read(), 1)
-    hc, ho = head.codes[:head.offs[1000]].copy(), head.offs[:1001].copy()
+    hc, ho = head.codes.copy(), head.offs.copy()
     head.close()
     c = TagdustHip(0)
     try:
