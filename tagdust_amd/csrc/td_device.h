@@ -113,7 +113,7 @@ struct TdSpecLayout {
 	int64_t dp;      // f32   [lmax][H][64]
 	int64_t path;    // u32   [lmax][ceil(H/4)][64]   four path bytes per word
 	int64_t total;   // f32   [H][64]
-	int64_t dust;    // (unused)
+	int64_t rs;      // f32   [2*C][64]  restarted sweeps: (M, I) rows of every column at the position a regular sweep takes over
 	int64_t bm;      // f32   [lmax+2][64]  running maximum of the first segment's label sums (kFirstN > 0)
 	int64_t ba;      // u8    [lmax+2][64]  the label holding it
 	int64_t acc;     // f32   [2][H][64]  label-DP rows (previous / current position) when too many labels for registers

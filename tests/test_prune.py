@@ -286,3 +286,27 @@ def test_reads_beyond_the_bound_tables_decode_densely():
         assert np.array_equal(res[k].view(np.uint32), ores[k].view(np.uint32)), k
     assert np.array_equal(labels, olab) and np.array_equal(seq_after, oseq)
     assert np.array_equal(res["read_type"], ores["read_type"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,n", [("c3", 1 << 15), ("c2", 1 << 15), ("c5", 1 << 13)], ids=["config3", "config2", "config5"])
+def test_restarted_sweeps_are_exact_or_fall_back(workload, n):
+    """TDS_RESTART (off by default, td_spec_kernel.inc "Restarted sweeps"): the leading segments' backward sweep and the trailing
+    segments' forward sweep start W positions before the first position their values are used at, from the interval
+    [-inf, host bound], and hand over to the plain sweep once every interval has closed.  With W = 40 every bridge closes and
+    the outputs are those of the dense sweeps, bit for bit; with W = 2 none can close, every tile takes the dense second pass,
+    and the outputs are still the same."""
+    dense = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_STATS": "0"})
+    on = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_STATS": "1", "TD_SPEC_EXTRA_OPTS": "-DTDS_RESTART=1 -DTDS_RESTART_W=40"})
+    assert _same(dense, on)
+    d = on[3]
+    tiles = (n + 63) // 64
+    assert d[206 - 192] == tiles and d[207 - 192] == 0                     # backward: restarted in every tile, none failed
+    assert d[197 - 192] > 0 and 3 < d[196 - 192] / d[197 - 192] < 40       # bridges closed well inside W
+    if workload != "c2":                                                   # (config 2 has no segment behind its read segment)
+        assert d[198 - 192] == tiles and d[199 - 192] == 0                 # forward likewise
+    assert d[238 - 192] == 0                                               # no dense second pass
+    short = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_STATS": "1", "TD_SPEC_EXTRA_OPTS": "-DTDS_RESTART=1 -DTDS_RESTART_W=2"})
+    assert _same(dense, short)
+    d = short[3]
+    assert d[207 - 192] > 0 and d[238 - 192] == tiles                      # every restarted tile failed to close and was decoded densely

@@ -31,6 +31,9 @@ for prune, stats in ((0, 0), (1, 0), (1, 1), (0, 0), (1, 0)):
         sx = cnt[224 - 192:228 - 192]
         note = "  trailing: decisions %d (mean required stop %.1f) fall-backs %d mean stop %.1f |" % (sx[0], sx[1] / max(sx[0], 1), sx[2], sx[3] / max(cnt[236 - 192], 1))
         note += "  lanes failing wa/wb/tot %s" % cnt[228 - 192:231 - 192].tolist()
+        rsx = cnt[194 - 192:200 - 192]
+        note += "  restarts: backward tiles %d (failed %d), bridges %d (mean interval steps %.1f) | forward tiles %d (failed %d), bridges %d (mean interval steps %.1f) |" % (
+            cnt[206 - 192], cnt[207 - 192], rsx[3], rsx[2] / max(rsx[3], 1), rsx[4], rsx[5], rsx[1], rsx[0] / max(rsx[1], 1))
         note += "  decisions %d (mean required cut %.1f)  spill too short %d  failed checks %d | tiles %d  mean cut %.1f  dense %d  mean spill cut %.1f" % (
             d[0], d[1] / max(d[0], 1), d[2], d[3], t[0], t[1] / max(t[0], 1), t[2], t[3] / max(t[0], 1))
     if base is None:
