@@ -127,7 +127,9 @@ int td_set_option(td_ctx* ctx, const char* name, int32_t value);
  * for models without a read segment behind a bounded prefix, for reads beyond 8192 bases, before the first batch) and
  * "overlap_active" (1 when pipelined batches really alternate between two compute streams and workspaces; 0 when the option
  * is off, the pipeline is one deep, the generic kernel runs, or HBM could not hold the second workspace);
- * "artifacts_active" (1 while a -ref artifact filter is set, td_set_artifacts). */
+ * "artifacts_active" (1 while a -ref artifact filter is set, td_set_artifacts); "length_classes" (the number of wave slots
+ * that were laid out for the last batch's longest read while the others kept the geometry of the reads at the 99 % mark --
+ * a batch with a few very long reads among many short ones; 0: one geometry). */
 int td_get_option(td_ctx* ctx, const char* name, int32_t* value);
 /* The HIP source td_model_upload would compile for this model (no GPU needed).  Returns its length; copies at
  * most cap-1 bytes + NUL into buf when buf != NULL. */

@@ -66,6 +66,11 @@ struct TdSlot {
 	TdSpecLayout slay{};
 	int32_t n_wave_slots = 0;
 	int64_t ws_slot_bytes = 0;
+	// length classes (specialised kernel): the n_long longest tiles are longer than lmax_small, the geometry of most wave slots;
+	// n_big >= n_long slots keep the geometry of the batch's longest read (slay_big).  n_long = 0: one geometry.
+	int32_t n_long = 0, lmax_small = 0, n_big = 0;
+	TdSpecLayout slay_big{};
+	int64_t ws_bytes = 0;       // workspace bytes this batch's launch uses
 	hipStream_t cs = nullptr;   // the compute stream this batch runs on (c->stream, or c->stream2 for every other pipelined batch)
 	hipStream_t aux = nullptr;  // the stream of its sort / pack kernels: cs itself, or the context's high-priority stream for them
 	hipStream_t fin = nullptr;  // ... and of its finish kernel (a stream of its own: it waits for the decode kernel, the next batch's pack must not)
@@ -623,6 +628,7 @@ extern "C" int td_get_option(td_ctx* c, const char* name, int32_t* value)
 	if (!strcmp(name, "pipeline_depth")) { *value = c->pipeline_depth; return TD_OK; }
 	if (!strcmp(name, "host_threads")) { *value = c->host_threads; return TD_OK; }
 	if (!strcmp(name, "artifacts_active")) { *value = c->art_n > 0; return TD_OK; }
+	if (!strcmp(name, "length_classes")) { *value = c->slots[c->last_slot].n_big; return TD_OK; }   // wave slots of the long geometry in the last batch
 	if (!strcmp(name, "overlap_decode")) { *value = c->overlap; return TD_OK; }
 	// which fast paths the model / the last batch actually got (read-only)
 	if (!strcmp(name, "prune_active")) {
@@ -780,7 +786,8 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 		td_model_desc md{};
 		md.S = c->hdr.S; md.H = c->hdr.H; md.C = c->hdr.C;
 		md.n_hmm = c->m_n_hmm.data(); md.n_col = c->m_n_col.data(); md.trans = c->m_trans.data();
-		td_spec_layout(s.slay, &md, s.lmax);
+		td_spec_layout(s.slay, &md, s.n_long > 0 ? s.lmax_small : s.lmax);   // the geometry of the many
+		td_spec_layout(s.slay_big, &md, s.lmax);
 		slot_bytes = s.slay.slot_bytes;
 		if (s.lmax > c->prune_lcap || !c->d_prune) {
 			// bound tables of the position pruning, for reads up to lcap bases (kernels in flight read the old ones)
@@ -807,23 +814,44 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 	if (slots > s.n_tiles) slots = s.n_tiles;
 	if (slots < 1) slots = 1;
 	slots = (slots + wpb - 1) / wpb * wpb; // whole workgroups
+	// length classes: the long tiles need a slot each of the big geometry (they are the first tiles the lowest slots take); when
+	// they are too many for that to pay -- more than a quarter of the slots -- the batch keeps one geometry
+	s.n_big = 0;
+	int64_t big_extra = 0;       // bytes the big slots take beyond a small slot each
+	if (c->spec_ready && s.n_long > 0) {
+		if ((int64_t)s.n_long * 4 <= slots) {
+			s.n_big = s.n_long;
+			big_extra = (int64_t)s.n_big * (s.slay_big.slot_bytes - s.slay.slot_bytes);
+		} else {
+			s.n_long = 0; s.lmax_small = s.lmax;
+			s.slay = s.slay_big;
+			slot_bytes = s.slay.slot_bytes;
+		}
+	}
 	uint8_t*& ws = s.wsi ? c->d_ws2 : c->d_ws;
 	size_t& cap_ws = s.wsi ? c->cap_ws2 : c->cap_ws;
-	if ((size_t)(slots * slot_bytes) > cap_ws) {
+	if ((size_t)(slots * slot_bytes + big_extra) > cap_ws) {
 		size_t free_b = 0, total_b = 0;
 		HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-		if (s.wsi == 1 && (double)(slots * slot_bytes) > 0.4 * (double)(free_b + cap_ws)) {
+		if (s.wsi == 1 && (double)(slots * slot_bytes + big_extra) > 0.4 * (double)(free_b + cap_ws)) {
 			// HBM cannot hold a second workspace of this size beside the first: this and all later batches run on the first stream
 			c->overlap = 0;
 			s.wsi = 0; s.cs = c->stream;
 			return ensure_workspace(c, s);
 		}
 		const int64_t budget = (int64_t)((double)(free_b + cap_ws) * 0.85);
-		if (slots * slot_bytes > budget) slots = budget / slot_bytes / wpb * wpb;
-		if (slots < wpb) return fail(c, "td_batch_upload: workspace of %lld bytes per wave does not fit in HBM", (long long)slot_bytes);
-		if ((size_t)(slots * slot_bytes) > cap_ws) {
+		if (slots * slot_bytes + big_extra > budget) {
+			if (big_extra > budget / 2) {   // not even the long tiles' slots fit beside a useful number of others: one geometry
+				s.n_long = 0; s.lmax_small = s.lmax; s.n_big = 0; big_extra = 0;
+				s.slay = s.slay_big;
+				slot_bytes = s.slay.slot_bytes;
+			}
+			slots = (budget - big_extra) / slot_bytes / wpb * wpb;
+		}
+		if (slots < wpb || slots < s.n_big) return fail(c, "td_batch_upload: workspace of %lld bytes per wave does not fit in HBM", (long long)slot_bytes);
+		if ((size_t)(slots * slot_bytes + big_extra) > cap_ws) {
 			HIPCHK(c, sync_compute(c));
-			const size_t need = (size_t)(slots * slot_bytes);
+			const size_t need = (size_t)(slots * slot_bytes + big_extra);
 			// Where the driver places a large allocation decides how fast the kernel's spill stream runs over it (up to
 			// 9 % on one box).  A large workspace is therefore chosen among a few candidates that
 			// exist side by side: a memory-side probe runs over each, the fastest stays, the others are freed.
@@ -855,6 +883,7 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 	}
 	s.n_wave_slots = (int32_t)slots;
 	s.ws_slot_bytes = slot_bytes;
+	s.ws_bytes = slots * slot_bytes + big_extra;
 	return TD_OK;
 }
 
@@ -888,6 +917,29 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 	if (bad >= 0) return fail(c, "td_batch_upload: read %lld has length %lld", (long long)bad, (long long)(offs[bad + 1] - offs[bad]));
 	const int64_t n_bases = n > 0 ? offs[n] - base : 0;
 	const int64_t n_tiles = (n + TD_WAVE - 1) / TD_WAVE;
+	// Length classes.  The reads are sorted by length on the device, so tile t holds the reads ranked 64 t .. 64 t + 63: from the
+	// histogram of the lengths, the longest read of every tile.  When the batch's longest read is at least half as long again as
+	// the reads at the 99 % mark, the tiles beyond that mark (n_long of them) get wave slots of their own geometry and the rest
+	// keeps the geometry of the many -- one 1000-base read among 150-base reads no longer costs every slot 6.6 times the memory.
+	s.n_long = 0; s.lmax_small = lmax;
+	if (c->spec_ready && with_workspace && lmin != lmax && n_tiles >= 64 && !getenv("TD_NO_LENGTH_CLASSES")) {
+		std::vector<int64_t> hist((size_t)lmax + 2, 0);
+		for (int64_t i = 0; i < n; i++) hist[(size_t)(offs[i + 1] - offs[i])]++;
+		// rank of the last read of the tile at the 99 % mark, its length, and the tiles that hold anything longer
+		const int64_t t99 = n_tiles - 1 - (n_tiles + 99) / 100;
+		const int64_t rank = t99 * TD_WAVE + TD_WAVE - 1;
+		int64_t acc = 0;
+		int l99 = lmax;
+		for (int l = 0; l <= lmax; l++) { acc += hist[(size_t)l]; if (acc > rank) { l99 = l; break; } }
+		if (l99 < 1) l99 = 1;
+		if ((int64_t)lmax * 2 >= (int64_t)l99 * 3) {
+			int64_t upto = 0;   // reads of length <= l99
+			for (int l = 0; l <= l99; l++) upto += hist[(size_t)l];
+			const int64_t first_long_tile = upto / TD_WAVE;                 // (a tile that mixes both kinds counts as long)
+			s.n_long = (int32_t)(n_tiles - first_long_tile);
+			s.lmax_small = l99;
+		}
+	}
 	const int nw2 = (lmax + 15) / 16, nw1 = (lmax + 31) / 32;
 	const bool sorted = n > 0 && lmin != lmax;
 
@@ -981,7 +1033,7 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 	}
 	// tests: every byte of the workspace the kernel reads must have been written by this launch -- garbage (NaN floats,
 	// all-ones masks) in place of whatever an earlier batch or model left there makes a read-before-write show
-	if (c->poison) HIPCHK(c, hipMemsetAsync(ka.ws, 0xFF, (size_t)s.n_wave_slots * (size_t)s.ws_slot_bytes, s.cs));
+	if (c->poison) HIPCHK(c, hipMemsetAsync(ka.ws, 0xFF, (size_t)s.ws_bytes, s.cs));
 	if (c->spec_ready) {   // the tile counter of the dynamic tile assignment starts at zero (the first tiles go by slot number)
 		int32_t*& tn = s.wsi ? c->d_tile_next2 : c->d_tile_next;
 		if (!tn) HIPCHK(c, hipMalloc((void**)&tn, 256));
@@ -999,6 +1051,8 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 		sa.out_keep = ka.out_keep; sa.out_labels = ka.out_labels; sa.counters = ka.counters;
 		sa.art_text = ka.art_text; sa.art_index = ka.art_index; sa.art_left = ka.art_left; sa.art_n = ka.art_n; sa.art_fe = ka.art_fe;
 		sa.ws = ka.ws; sa.lay = s.slay;
+		sa.lmax = s.n_big > 0 ? s.lmax_small : s.lmax;
+		sa.n_big = s.n_big; sa.lmax_big = s.lmax; sa.lay_big = s.slay_big; sa.out_lmax = s.lmax;
 		sa.prune = c->d_prune; sa.prune_stride = c->prune_stride;
 		sa.tile_next = s.wsi ? c->d_tile_next2 : c->d_tile_next;
 		size_t sz = sizeof sa;
@@ -1344,7 +1398,7 @@ extern "C" int td_batch_info(td_ctx* c, int64_t* n_reads, int64_t* workspace_byt
 	if (!c) return TD_FAIL;
 	const TdSlot& s = c->slots[c->last_slot];
 	if (n_reads) *n_reads = s.n_reads;
-	if (workspace_bytes) *workspace_bytes = (int64_t)s.n_wave_slots * s.ws_slot_bytes;
+	if (workspace_bytes) *workspace_bytes = s.ws_bytes ? s.ws_bytes : (int64_t)s.n_wave_slots * s.ws_slot_bytes;
 	if (wave_slots) *wave_slots = s.n_wave_slots;
 	return TD_OK;
 }

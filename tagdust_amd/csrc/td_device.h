@@ -152,4 +152,11 @@ struct TdSpecArgs {
 	// position pruning (td_spec_kernel.inc): four host tables of prune_stride floats each -- fb[i], bwb[m], wa[i], wb[i]
 	const float* __restrict__ prune;
 	int32_t* __restrict__ tile_next;   // tiles handed out so far beyond the first n_slots (dynamic tile assignment): zero before the launch
+	// Length classes: a batch whose longest reads are far longer than the rest (one 1000-base read among 150-base ones) keeps the
+	// workspace geometry of the many.  Wave slots [0, n_big) are laid out for the batch's longest read (lay_big, lmax_big) and
+	// sit in front of the others in `ws`; slots take their first tile by slot number, longest tiles first, so the n_long <= n_big
+	// tiles longer than `lmax` (the geometry of the other slots) all start in a big slot.  n_big = 0: one geometry (lay, lmax).
+	int32_t n_big, lmax_big;
+	int32_t out_lmax;                  // stride of out_labels (the batch's longest read), whatever geometry a slot has
+	TdSpecLayout lay_big;
 };

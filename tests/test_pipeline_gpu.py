@@ -285,3 +285,69 @@ def test_page_locked_input_may_be_reused_after_submit():
         c.close()
         ref.close()
         pin.free()
+
+
+def test_length_outliers_get_their_own_wave_slots(monkeypatch):
+    """A batch of 150-base reads with 0.1 % reads of 1000 bases: the workspace keeps the geometry of the many (the long tiles get
+    wave slots of their own), both pipeline streams stay in use, and every output byte equals what one geometry for all gives
+    (TD_NO_LENGTH_CLASSES=1) -- and the oracle, on a sample that holds every long read."""
+    import bench
+    from oracle import pyoracle
+    from tagdust_amd import TagdustHip, RESULT_DTYPE
+    bench.select_workload("c3")
+    g = bench.load_model()
+    rng = np.random.default_rng(77)
+    n, L = 1 << 17, bench.READ_LEN
+    short = bench.synth_batch(n, 99)
+    n_long = n // 1000
+    at = set(rng.choice(n, n_long, replace=False).tolist())
+    reads = []
+    for i in range(n):
+        if i in at:                     # the same kind of read with a 1000-base insert
+            r = np.concatenate([short[i][:9], rng.integers(0, 4, 1000 - L, dtype=np.uint8), short[i][9:]])
+            reads.append(r)
+        else:
+            reads.append(short[i])
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    seq = np.concatenate(reads).astype(np.uint8)
+
+    def run(no_classes):
+        if no_classes:
+            monkeypatch.setenv("TD_NO_LENGTH_CLASSES", "1")
+        else:
+            monkeypatch.delenv("TD_NO_LENGTH_CLASSES", raising=False)
+        c = _ctx(g, 1, depth=3)
+        try:
+            outs = []
+            for _ in range(2):          # two batches: both streams / workspaces
+                res = np.zeros(n, RESULT_DTYPE)
+                lab = np.zeros(int(offs[-1]) + n, np.int8)
+                sq = np.zeros(int(offs[-1]), np.uint8)
+                outs.append((res, lab, sq, c.submit(seq, offs, res=res, labels=lab, seq_out=sq)))
+            for o in outs:
+                c.wait(o[3])
+            return outs, c.get_option("length_classes"), c.batch_info()[1], c.get_option("overlap_active")
+        finally:
+            c.close()
+
+    one, k1, ws1, ov1 = run(True)
+    two, k2, ws2, ov2 = run(False)
+    assert k1 == 0 and 1 <= k2 <= 4 * (n_long + 2) and ov2 == 1
+    assert ws2 * 3 < ws1                                     # (1000-base geometry for every slot: 6.6 x the memory)
+    for a, b in zip(one, two):
+        assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert one[0][0].tobytes() == one[1][0].tobytes()
+    pick = np.sort(np.concatenate([np.fromiter(at, np.int64), rng.choice(n, 400, replace=False)]))
+    pick = np.unique(pick)
+    pseq = np.concatenate([reads[i] for i in pick]).astype(np.uint8)
+    poffs = np.concatenate([[0], np.cumsum([len(reads[i]) for i in pick])]).astype(np.int64)
+    om = pyoracle.OracleModel(g)
+    ores, olab, oseq = pyoracle.label_batch(om, pseq, poffs, float(g["threshold"]), int(g["minlen"]), int(g["dust"]), 8)
+    res = two[0][0][pick]
+    for k, ok_ in (("b_score", "b_score"), ("f_score", "f_score"), ("r_score", "r_score"), ("bar_prob", "bar_prob"), ("mapq", "Q")):
+        assert np.array_equal(_bits(res[k]), _bits(ores[ok_])), k
+    for k in ("read_type", "barcode", "fingerprint"):
+        assert np.array_equal(res[k], ores[k])
+    lab = np.concatenate([two[0][1][offs[i] + i: offs[i + 1] + i + 1] for i in pick])
+    sq = np.concatenate([two[0][2][offs[i]: offs[i + 1]] for i in pick])
+    assert np.array_equal(lab, olab) and np.array_equal(sq, oseq)
