@@ -61,6 +61,7 @@ struct TdSlot {
 	bool res_direct = false, lab_direct = false, seq_direct = false;                          // ... are page-locked
 	bool copies_deferred = false;   // td_wait issues the device-to-host copies (pipelined calls)
 	bool raw_direct = false;        // the upload reads the caller's page-locked buffer itself (no staging copy)
+	bool pipelined = false;         // a td_submit batch (the synchronous calls use slot 0 with pipelined = false)
 	TdStageBatch sb{};
 	TdWsLayout lay{};
 	TdSpecLayout slay{};
@@ -234,6 +235,7 @@ struct td_ctx {
 	uint8_t* d_ws2 = nullptr;     size_t cap_ws2 = 0;
 	int32_t* d_tile_next2 = nullptr;
 	int overlap = 1, submit_parity = 0;
+	bool half_slots = false;   // two workspaces of the full slot count do not fit: the pipelined launches use half the slots each
 	// position pruning tables of the specialised kernel (td_spec_prune_tables), for reads up to prune_lcap bases
 	float* d_prune = nullptr;     int prune_lcap = 0, prune_stride = 0;
 	bool prune_live = false;      // ... and they are real bounds (not the all-zero tables of reads beyond 8192 bases)
@@ -558,6 +560,7 @@ extern "C" int td_model_upload(td_ctx* c, const td_model_desc* m)
 	if (c->spec_mod) { HIPCHK(c, hipModuleUnload(c->spec_mod)); c->spec_mod = nullptr; }
 	c->spec_fn = nullptr; c->spec_ready = false;
 	c->prune_lcap = 0; c->prune_live = false;   // the pruning tables belong to the model
+	c->half_slots = false;                      // ... and so does the workspace geometry
 	if (c->specialize) {
 		// keep what a later recompile needs
 		c->m_skip.assign(m->skip, m->skip + m->S);
@@ -830,10 +833,24 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 	}
 	uint8_t*& ws = s.wsi ? c->d_ws2 : c->d_ws;
 	size_t& cap_ws = s.wsi ? c->cap_ws2 : c->cap_ws;
+	// Pipelined batches overlap their launches on two streams with a workspace each.  When HBM cannot hold two workspaces of the
+	// full wave-slot count (config 5: 42 MiB per slot, 172 GB for 4096 slots) each launch gets half the slots instead -- two
+	// launches side by side still fill every SIMD, and the machine stays busy while one launch's slowest waves finish.
+	if (s.pipelined && c->overlap && c->pipeline_depth > 1 && c->spec_ready && !c->half_slots) {
+		size_t free_b = 0, total_b = 0;
+		HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+		const double avail = (double)free_b + (double)c->cap_ws + (double)c->cap_ws2;
+		if (2.0 * (double)(slots * slot_bytes + big_extra) > 0.8 * avail && (double)(slots * slot_bytes + big_extra) <= 0.8 * avail) c->half_slots = true;
+	}
+	if (c->half_slots && s.pipelined) {
+		int64_t half = (slots / 2 + wpb - 1) / wpb * wpb;
+		if (half < wpb) half = wpb;
+		if (half >= s.n_big * 4 || s.n_big == 0) slots = half;
+	}
 	if ((size_t)(slots * slot_bytes + big_extra) > cap_ws) {
 		size_t free_b = 0, total_b = 0;
 		HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-		if (s.wsi == 1 && (double)(slots * slot_bytes + big_extra) > 0.4 * (double)(free_b + cap_ws)) {
+		if (s.wsi == 1 && (double)(slots * slot_bytes + big_extra) > (c->half_slots ? 0.6 : 0.4) * (double)(free_b + cap_ws)) {
 			// HBM cannot hold a second workspace of this size beside the first: this and all later batches run on the first stream
 			c->overlap = 0;
 			s.wsi = 0; s.cs = c->stream;
@@ -1140,7 +1157,7 @@ static int upload_common(td_ctx* c, const void* bases, int is_ascii, const int64
 	if (!c) return TD_FAIL;
 	if (tickets_outstanding(c)) return fail(c, "td_batch_upload: td_submit tickets are outstanding (td_wait them first)");
 	TdSlot& s = c->slots[0];
-	s.cs = c->stream; s.wsi = 0; s.aux = c->stream; s.fin = c->stream;
+	s.cs = c->stream; s.wsi = 0; s.aux = c->stream; s.fin = c->stream; s.pipelined = false;
 	if (slot_stage(c, s, bases, is_ascii, offs, n, c->stream) != TD_OK) return TD_FAIL;
 	HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller may reuse its buffers
 	c->last_slot = 0;
@@ -1203,7 +1220,7 @@ extern "C" int td_submit(td_ctx* c, const void* bases, int32_t is_ascii, const i
 	}
 	if (k < 0) return fail(c, "td_submit: all %d pipeline slots hold batches that have not been waited for", c->pipeline_depth);
 	TdSlot& s = c->slots[k];
-	s.cs = c->stream; s.wsi = 0; s.aux = c->stream; s.fin = c->stream;
+	s.cs = c->stream; s.wsi = 0; s.aux = c->stream; s.fin = c->stream; s.pipelined = true;
 	if (c->overlap && c->pipeline_depth > 1 && c->spec_ready) {   // every other batch on the second stream / workspace
 		if (!c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
 		if (c->submit_parity) { s.cs = c->stream2; s.wsi = 1; }
