@@ -282,8 +282,10 @@ def e2e_stream(dev_index, copies=4, n=1 << 20, n_threads=0, keep_dir=None):
             "parse_stage_reads_per_s": rate(st["parse_s"]), "write_stage_reads_per_s": rate(st["write_s"]),
             "decode_thread_busy_s": st["decode_s"], "parse_busy_s": st["parse_s"], "write_busy_s": st["write_s"], "read_wait_s": st["read_s"],
             "wall_over_slowest_host_stage": (max(st["parse_s"], st["write_s"]) / st["wall_s"]) if st["wall_s"] > 0 else None,
-            "what": "td_stream_run on a %d x %d-read FASTQ file in a temporary directory (page cache), batches of 1 000 001 reads, "
-                    "model + threshold given; wall includes opening the files and allocating the page-locked batch buffers" % (copies, n)}
+            "what": "td_stream_run on a %d x %d-read FASTQ file in a temporary directory (page cache), %d batches (2^18 reads each: no "
+                    "-ref filter, so the batching is free), model + threshold given, context warm (kernel compiled, workspaces and the "
+                    "page-locked batch buffers of a previous file in place); wall includes mapping the input and creating the output files"
+                    % (copies, n, st["n_batches"])}
 
 
 class _DevCounters:
@@ -407,20 +409,21 @@ def measure_workload(name, n, steps, warmup, dev_index, specialize=1, depth=2, p
         ctx.timeline_origin()
         state["k_ms"] = run_pipelined(ctx, host_batches, o, n_steps or steps, depth, state["timeline"])
 
-    def kernel_only():
+    def kernel_only(n_steps=None):
         """The decode kernel alone over a resident batch (round 1's figure), outside the timed region."""
-        if not kernel_only_steps:
+        n_steps = n_steps or kernel_only_steps
+        if not n_steps:
             return None
         ctx.upload_batch(host_batches[0][0], host_batches[0][1])
         ms = []
         ctx.run(); ctx.sync()
         t0 = time.perf_counter()
-        for _ in range(kernel_only_steps):
+        for _ in range(n_steps):
             ctx.run()
             ms.append(ctx.last_kernel_ms())
         ctx.sync()
         dt = time.perf_counter() - t0
-        return {"value": n * kernel_only_steps / dt, "unit": "reads/s", "kernel_ms": float(np.mean(ms)), "steps": kernel_only_steps,
+        return {"value": n * n_steps / dt, "unit": "reads/s", "kernel_ms": float(np.mean(ms)), "steps": n_steps,
                 "note": "decode kernel alone, batch resident in HBM, no transfers (round 1's headline definition)"}
 
     def close():
@@ -514,6 +517,8 @@ def main():
     ap.add_argument("--labels", type=int, default=1, help="0 = the timed region does not download the per-base labels (rounds 1-2)")
     ap.add_argument("--sustained", type=int, default=200, help="steps of the extra sustained run (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="0 = skip the extra measurements (kernel only, pinned I/O, configs 2 and 5)")
+    ap.add_argument("--isolated", type=int, default=0, help="N > 0: nothing but N isolated launches of the decode kernel on a resident batch "
+                    "(what roofline.kernel_ms measures) -- the run tools/profile_lease.sh traces to hold rocprofv3's duration against it")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)      # does not return
@@ -570,6 +575,17 @@ def main():
         check=args.check, kernel_only_steps=5, labels=bool(args.labels))
     reduce_dev = torch.device("cuda", dev_index) if backend == "nccl" else None
     last_counts = [None]
+    if args.isolated > 0:
+        iso = kernel_only(args.isolated)
+        if rank == 0:
+            real_stdout.write(json.dumps({"isolated_launches": iso["steps"], "kernel": "td_spec_kernel" if args.specialize else "td_decode_kernel",
+                                          "kernel_ms": iso["kernel_ms"], "reads_per_launch": n, "workload": _ACTIVE["name"],
+                                          "kernel_reads_per_s": n / (iso["kernel_ms"] * 1e-3)}) + "\n")
+            real_stdout.flush()
+        close()
+        if use_dist:
+            dist.destroy_process_group()
+        return
 
     def reduce_counts():
         # the path's only exchange: the 264 per-outcome / per-barcode counters, summed over ranks once per run, as the

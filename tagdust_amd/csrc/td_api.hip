@@ -14,6 +14,7 @@
 
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -90,6 +91,13 @@ struct TdSlot {
 	uint8_t* d_res = nullptr;      size_t cap_res = 0;    // results in the caller's order
 	uint8_t* d_seq = nullptr;      size_t cap_seq = 0;
 	int8_t*  d_lab = nullptr;      size_t cap_lab = 0;
+	// compact egress: what the host rebuilds the rewritten sequences and the labels from (slot_fetch_begin)
+	uint32_t* d_keepo = nullptr;   size_t cap_keepo = 0;
+	uint32_t* d_rle = nullptr;     size_t cap_rle = 0;     // (+ one word behind the runs: the overflow flag)
+	uint32_t* h_keepo = nullptr;   size_t cap_h_keepo = 0;
+	uint32_t* h_rle = nullptr;     size_t cap_h_rle = 0;
+	bool use_keep = false, use_rle = false;
+	int32_t rle_cap = 0;
 	// pinned host staging for pageable caller memory
 	uint8_t* h_raw = nullptr;      size_t cap_h_raw = 0;
 	int64_t* h_offs = nullptr;     size_t cap_h_offs = 0;
@@ -112,7 +120,7 @@ static int default_host_threads()
 
 // The copy threads of one context: started once, reused by every batch (the calling thread takes a share of each copy itself).
 struct CopyPool {
-	struct Job { char* dst; const char* src; size_t bytes; };
+	struct Job { char* dst; const char* src; size_t bytes; const std::function<void(int64_t, int64_t)>* fn; int64_t lo, hi; };
 	std::vector<std::thread> th;
 	std::mutex mu;
 	std::condition_variable cv_job, cv_done;
@@ -132,7 +140,7 @@ struct CopyPool {
 						if (q.empty()) return;   // stop
 						j = q.front(); q.pop_front();
 					}
-					memcpy(j.dst, j.src, j.bytes);
+					if (j.fn) (*j.fn)(j.lo, j.hi); else memcpy(j.dst, j.src, j.bytes);
 					{
 						std::lock_guard<std::mutex> lk(mu);
 						if (--pending == 0) cv_done.notify_all();
@@ -152,12 +160,29 @@ struct CopyPool {
 		{
 			std::lock_guard<std::mutex> lk(mu);
 			for (size_t lo = per; lo < bytes; lo += per) {
-				q.push_back(Job{ (char*)dst + lo, (const char*)src + lo, lo + per < bytes ? per : bytes - lo });
+				q.push_back(Job{ (char*)dst + lo, (const char*)src + lo, lo + per < bytes ? per : bytes - lo, nullptr, 0, 0 });
 				pending++;
 			}
 		}
 		cv_job.notify_all();
 		memcpy(dst, src, per < bytes ? per : bytes);
+		std::unique_lock<std::mutex> lk(mu);
+		cv_done.wait(lk, [this] { return pending == 0; });
+	}
+	// fn(lo, hi) over [0, n) in contiguous ranges on nt threads (this one included)
+	void ranges(int64_t n, int nt, const std::function<void(int64_t, int64_t)>& fn)
+	{
+		if (n <= 0) return;
+		if (nt > n / 4096) nt = (int)(n / 4096);
+		if (nt <= 1) { fn(0, n); return; }
+		start(nt - 1);
+		const int64_t per = (n + nt - 1) / nt;
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			for (int64_t lo = per; lo < n; lo += per) { q.push_back(Job{ nullptr, nullptr, 0, &fn, lo, lo + per < n ? lo + per : n }); pending++; }
+		}
+		cv_job.notify_all();
+		fn(0, per < n ? per : n);
 		std::unique_lock<std::mutex> lk(mu);
 		cv_done.wait(lk, [this] { return pending == 0; });
 	}
@@ -766,9 +791,9 @@ static int slot_events(td_ctx* c, TdSlot& s)
 static void slot_release(TdSlot& s)
 {
 	void* dev[] = { s.d_raw, s.d_offs, s.d_read_at, s.d_keys, s.d_vals, s.d_sort_tmp, s.d_packed, s.d_lens, s.d_art_left,
-	                s.d_out, s.d_res, s.d_seq, s.d_lab };
+	                s.d_out, s.d_res, s.d_seq, s.d_lab, s.d_keepo, s.d_rle };
 	for (void* p : dev) if (p) (void)hipFree(p);
-	void* pinned[] = { s.h_raw, s.h_offs, s.h_res, s.h_seq, s.h_lab };
+	void* pinned[] = { s.h_raw, s.h_offs, s.h_res, s.h_seq, s.h_lab, s.h_keepo, s.h_rle };
 	for (void* p : pinned) if (p) (void)hipHostFree(p);
 	hipEvent_t ev[] = { s.ev_up, s.ev_k0, s.ev_k1, s.ev_done, s.ev_down, s.ev_pack };
 	for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
@@ -1099,8 +1124,14 @@ static int slot_issue_copies(td_ctx* c, TdSlot& s, hipStream_t down)
 	const int64_t n = s.n_reads;
 	const size_t res_bytes = (size_t)n * sizeof(td_read_result), seq_bytes = (size_t)s.n_bases, lab_bytes = (size_t)(s.n_bases + n);
 	if (s.u_res) HIPCHK(c, hipMemcpyAsync(s.res_direct ? (void*)s.u_res : (void*)s.h_res, s.d_res, res_bytes, hipMemcpyDeviceToHost, down));
-	if (s.u_seq && seq_bytes) HIPCHK(c, hipMemcpyAsync(s.seq_direct ? (void*)s.u_seq : (void*)s.h_seq, s.d_seq, seq_bytes, hipMemcpyDeviceToHost, down));
-	if (s.u_labels) HIPCHK(c, hipMemcpyAsync(s.lab_direct ? (void*)s.u_labels : (void*)s.h_lab, s.d_lab, lab_bytes, hipMemcpyDeviceToHost, down));
+	if (s.u_seq && seq_bytes) {
+		if (s.use_keep) HIPCHK(c, hipMemcpyAsync(s.h_keepo, s.d_keepo, (size_t)n * (size_t)s.nw1 * 4, hipMemcpyDeviceToHost, down));
+		else HIPCHK(c, hipMemcpyAsync(s.seq_direct ? (void*)s.u_seq : (void*)s.h_seq, s.d_seq, seq_bytes, hipMemcpyDeviceToHost, down));
+	}
+	if (s.u_labels) {
+		if (s.use_rle) HIPCHK(c, hipMemcpyAsync(s.h_rle, s.d_rle, ((size_t)n * (size_t)s.rle_cap + 1) * 4, hipMemcpyDeviceToHost, down));
+		else HIPCHK(c, hipMemcpyAsync(s.lab_direct ? (void*)s.u_labels : (void*)s.h_lab, s.d_lab, lab_bytes, hipMemcpyDeviceToHost, down));
+	}
 	HIPCHK(c, hipEventRecord(s.ev_down, down));
 	return TD_OK;
 }
@@ -1114,15 +1145,35 @@ static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* l
 	const int64_t n = s.n_reads;
 	if (n == 0) return TD_OK;
 	const size_t res_bytes = (size_t)n * sizeof(td_read_result), seq_bytes = (size_t)s.n_bases, lab_bytes = (size_t)(s.n_bases + n);
+	// Compact egress.  The rewritten sequence is the input with some positions turned into the spacer byte: the keep bits (one
+	// per base) come back instead and the host rebuilds it from its staging copy of the input -- unless the caller's page-locked
+	// buffer was the DMA source, which the caller may have refilled since.  ri->labels is a handful of runs per read (the path
+	// moves through the segments in order): (length, label) pairs come back and the host expands them.  A fifth of the bytes
+	// over PCIe, and that much less work for the download's blit kernels, which compete with the decode kernel for CUs.
+	const bool compact = !(getenv("TD_COMPACT_EGRESS") && atoi(getenv("TD_COMPACT_EGRESS")) == 0);
+	s.use_keep = compact && seq_out && seq_bytes && !s.raw_direct && s.h_raw;
+	s.use_rle = compact && labels;
+	s.rle_cap = c->hdr.S + 2 < c->hdr.H ? c->hdr.S + 2 : c->hdr.H;      // runs <= labels visited; a path visits one label per segment
+	if (const char* e = getenv("TD_RLE_CAP")) { const int v = atoi(e); if (v >= 1 && v <= 127) s.rle_cap = v; }   // tests: force the overflow route
 	if (res && ensure(c, &s.d_res, &s.cap_res, res_bytes) != TD_OK) return TD_FAIL;
-	if (seq_out && ensure(c, &s.d_seq, &s.cap_seq, seq_bytes) != TD_OK) return TD_FAIL;
-	if (labels && ensure(c, &s.d_lab, &s.cap_lab, lab_bytes) != TD_OK) return TD_FAIL;
+	if (seq_out && !s.use_keep && ensure(c, &s.d_seq, &s.cap_seq, seq_bytes) != TD_OK) return TD_FAIL;
+	if (labels && !s.use_rle && ensure(c, &s.d_lab, &s.cap_lab, lab_bytes) != TD_OK) return TD_FAIL;
 	if (res && !(s.res_direct = is_pinned(res)) && ensure_pinned(c, &s.h_res, &s.cap_h_res, res_bytes) != TD_OK) return TD_FAIL;
-	if (seq_out && !(s.seq_direct = is_pinned(seq_out)) && ensure_pinned(c, &s.h_seq, &s.cap_h_seq, seq_bytes) != TD_OK) return TD_FAIL;
-	if (labels && !(s.lab_direct = is_pinned(labels)) && ensure_pinned(c, &s.h_lab, &s.cap_h_lab, lab_bytes) != TD_OK) return TD_FAIL;
+	if (seq_out && !s.use_keep && !(s.seq_direct = is_pinned(seq_out)) && ensure_pinned(c, &s.h_seq, &s.cap_h_seq, seq_bytes) != TD_OK) return TD_FAIL;
+	if (labels && !s.use_rle && !(s.lab_direct = is_pinned(labels)) && ensure_pinned(c, &s.h_lab, &s.cap_h_lab, lab_bytes) != TD_OK) return TD_FAIL;
+	const size_t keepo_bytes = (size_t)n * (size_t)s.nw1 * 4, rle_bytes = ((size_t)n * (size_t)s.rle_cap + 1) * 4;
+	if (s.use_keep && (ensure(c, &s.d_keepo, &s.cap_keepo, keepo_bytes) != TD_OK || ensure_pinned(c, &s.h_keepo, &s.cap_h_keepo, keepo_bytes) != TD_OK)) return TD_FAIL;
+	if (s.use_rle) {
+		if (ensure(c, &s.d_rle, &s.cap_rle, rle_bytes) != TD_OK || ensure_pinned(c, &s.h_rle, &s.cap_h_rle, rle_bytes) != TD_OK) return TD_FAIL;
+		HIPCHK(c, hipMemsetAsync(s.d_rle + (size_t)n * (size_t)s.rle_cap, 0, 4, s.fin));   // the overflow flag
+	}
 	s.sb.res = res ? s.d_res : nullptr;
-	s.sb.seq_out = seq_out ? s.d_seq : nullptr;
-	s.sb.labels_out = labels ? s.d_lab : nullptr;
+	s.sb.seq_out = (seq_out && !s.use_keep) ? s.d_seq : nullptr;
+	s.sb.labels_out = (labels && !s.use_rle) ? s.d_lab : nullptr;
+	s.sb.keep_out = s.use_keep ? s.d_keepo : nullptr;
+	s.sb.rle_out = s.use_rle ? s.d_rle : nullptr;
+	s.sb.rle_cap = s.rle_cap;
+	s.sb.rle_overflow = s.use_rle ? (int32_t*)(s.d_rle + (size_t)n * (size_t)s.rle_cap) : nullptr;
 	if (s.fin != s.cs) HIPCHK(c, hipStreamWaitEvent(s.fin, s.ev_k1, 0));
 	HIPCHK(c, td_stage_finish(s.sb, s.fin));
 	if (deferred) HIPCHK(c, hipEventRecord(s.ev_done, s.fin));
@@ -1140,9 +1191,58 @@ static int slot_fetch_end(td_ctx* c, TdSlot& s)
 	}
 	HIPCHK(c, hipEventSynchronize(s.ev_down));
 	const int64_t n = s.n_reads;
+	if (s.use_rle && s.u_labels && s.h_rle[(size_t)n * (size_t)s.rle_cap] != 0) {
+		// a read with more label runs than the table holds (a model whose labels are not one per segment): the labels as they are
+		const size_t lab_bytes = (size_t)(s.n_bases + n);
+		if (ensure(c, &s.d_lab, &s.cap_lab, lab_bytes) != TD_OK) return TD_FAIL;
+		if (!(s.lab_direct = is_pinned(s.u_labels)) && ensure_pinned(c, &s.h_lab, &s.cap_h_lab, lab_bytes) != TD_OK) return TD_FAIL;
+		TdStageBatch b2 = s.sb;
+		b2.res = nullptr; b2.seq_out = nullptr; b2.keep_out = nullptr; b2.rle_out = nullptr; b2.labels_out = s.d_lab;
+		HIPCHK(c, td_stage_finish(b2, s.fin));
+		HIPCHK(c, hipStreamSynchronize(s.fin));
+		HIPCHK(c, hipMemcpy(s.lab_direct ? (void*)s.u_labels : (void*)s.h_lab, s.d_lab, lab_bytes, hipMemcpyDeviceToHost));
+		s.use_rle = false;
+	}
 	if (s.u_res && !s.res_direct) parallel_copy(c, s.u_res, s.h_res, (size_t)n * sizeof(td_read_result));
-	if (s.u_seq && !s.seq_direct && s.n_bases) parallel_copy(c, s.u_seq, s.h_seq, (size_t)s.n_bases);
-	if (s.u_labels && !s.lab_direct) parallel_copy(c, s.u_labels, s.h_lab, (size_t)(s.n_bases + n));
+	if (s.u_seq && s.n_bases) {
+		if (s.use_keep) {
+			// make_extracted_read(), barcode_hmm.c:3343-3350, from the keep bits and the staged input (base codes as the device
+			// sees them: init_nuc_code for sequence text, anything above 4 is 4)
+			const int nw1 = s.nw1, ascii = s.is_ascii;
+			const uint8_t* raw = s.h_raw; const int64_t* offs = s.h_offs; const uint32_t* kb = s.h_keepo; uint8_t* out = s.u_seq;
+			static const struct Lut { uint8_t t[256]; Lut() { for (int k = 0; k < 256; k++) t[k] = 4; t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = t['U'] = t['u'] = 3; } } lut;
+			const std::function<void(int64_t, int64_t)> fn = [=](int64_t lo, int64_t hi) {
+				for (int64_t i = lo; i < hi; i++) {
+					const int64_t o = offs[i];
+					const int len = (int)(offs[i + 1] - o);
+					const uint32_t* kw = kb + i * nw1;
+					for (int p0 = 0; p0 < len; p0 += 32) {
+						const uint32_t w = kw[p0 >> 5];
+						const int e = len - p0 < 32 ? len - p0 : 32;
+						const uint8_t* src = raw + o + p0; uint8_t* dst = out + o + p0;
+						if (w == 0u) { memset(dst, 65, (size_t)e); continue; }
+						if (ascii) { for (int q = 0; q < e; q++) dst[q] = ((w >> q) & 1u) ? lut.t[src[q]] : (uint8_t)65; }
+						else { for (int q = 0; q < e; q++) { const uint8_t cd = src[q] > 4 ? (uint8_t)4 : src[q]; dst[q] = ((w >> q) & 1u) ? cd : (uint8_t)65; } }
+					}
+				}
+			};
+			c->pool.ranges(n, c->host_threads, fn);
+		} else if (!s.seq_direct) parallel_copy(c, s.u_seq, s.h_seq, (size_t)s.n_bases);
+	}
+	if (s.u_labels) {
+		if (s.use_rle) {
+			const int cap = s.rle_cap;
+			const int64_t* offs = s.h_offs; const uint32_t* rl = s.h_rle; int8_t* out = s.u_labels;
+			const std::function<void(int64_t, int64_t)> fn = [=](int64_t lo, int64_t hi) {
+				for (int64_t i = lo; i < hi; i++) {
+					int8_t* p = out + offs[i] + i;
+					const uint32_t* r = rl + i * cap;
+					for (int j = 0; j < cap && r[j]; j++) { const size_t len = r[j] >> 8; memset(p, (int)(int8_t)(r[j] & 0xFF), len); p += len; }
+				}
+			};
+			c->pool.ranges(n, c->host_threads, fn);
+		} else if (!s.lab_direct) parallel_copy(c, s.u_labels, s.h_lab, (size_t)(s.n_bases + n));
+	}
 	return TD_OK;
 }
 

@@ -33,6 +33,11 @@ struct TdStageBatch {
 	uint8_t* res;             // [n] td_read_result (32 B)
 	uint8_t* seq_out;         // [offs[n]]
 	int8_t*  labels_out;      // [offs[n] + n]
+	// ... or, for the two big ones, what the host can rebuild them from (a fifth of the bytes over PCIe):
+	uint32_t* keep_out;       // [n][nw1] the keep bits of read i (bit p: base p stays, else it becomes the spacer byte 65)
+	uint32_t* rle_out;        // [n][rle_cap] the runs of ri->labels[0..len]: (run length << 8) | label, unused entries 0
+	int32_t   rle_cap;
+	int32_t*  rle_overflow;   // set to 1 when a read has more than rle_cap runs (the host then asks for labels_out)
 };
 
 // bytes of scratch td_stage_sort needs for n reads

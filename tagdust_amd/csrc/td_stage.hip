@@ -163,6 +163,32 @@ __global__ __launch_bounds__(STAGE_BLOCK) void td_finish_kernel(const TdStageBat
 			}
 		}
 		s_off[lane] = o; s_idx[lane] = i; s_len[lane] = len;
+		if (b.keep_out && k < b.n_reads) {
+			const uint32_t* kw = b.keep + (int64_t)tile * b.nw1 * TD_WAVE;
+			for (int w = 0; w < b.nw1; w++) b.keep_out[i * b.nw1 + w] = kw[w * TD_WAVE + lane];
+		}
+		if (b.rle_out) {
+			// the label path of a read is a handful of runs (it moves through the segments in order): (length, label) pairs
+			const int8_t* lb = b.labels + (int64_t)tile * (b.lmax + 1) * TD_WAVE;
+			uint32_t* dst = (k < b.n_reads) ? b.rle_out + i * b.rle_cap : nullptr;
+			int nr = 0, run = 0, cur = 0;
+			int lmx = len;
+			for (int o2 = 32; o2 >= 1; o2 >>= 1) { const int t2 = __shfl_xor(lmx, o2); lmx = t2 > lmx ? t2 : lmx; }
+			for (int p = 0; p <= lmx; p++) {
+				const int v = (len >= 1 && p <= len) ? (int)lb[p * TD_WAVE + lane] : 0;   // (a read without bases has the one label 0)
+				if (p <= len || (p == 0 && len < 1)) {
+					if (p == 0) { cur = v; run = 1; }
+					else if (v == cur) run++;
+					else { if (dst && nr < b.rle_cap) dst[nr] = ((uint32_t)run << 8) | (uint32_t)(cur & 0xFF); nr++; cur = v; run = 1; }
+				}
+			}
+			if (dst) {
+				if (nr < b.rle_cap) dst[nr] = ((uint32_t)run << 8) | (uint32_t)(cur & 0xFF);
+				nr++;
+				for (int j = nr; j < b.rle_cap; j++) dst[j] = 0u;
+				if (nr > b.rle_cap) atomicOr(b.rle_overflow, 1);
+			}
+		}
 	}
 	__syncthreads();
 	if (b.seq_out) {

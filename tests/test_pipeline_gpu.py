@@ -351,3 +351,52 @@ def test_length_outliers_get_their_own_wave_slots(monkeypatch):
     lab = np.concatenate([two[0][1][offs[i] + i: offs[i + 1] + i + 1] for i in pick])
     sq = np.concatenate([two[0][2][offs[i]: offs[i + 1]] for i in pick])
     assert np.array_equal(lab, olab) and np.array_equal(sq, oseq)
+
+
+@pytest.mark.parametrize("name", ["c3_b6_s_r_p", "c2_indel_varlen", "window_b_r", "b_r_s_r"])
+def test_compact_egress_equals_plain_copies(name, monkeypatch):
+    """The rewritten sequences and the labels come back as keep bits and label runs and are rebuilt on the host (td_api.hip
+    "Compact egress"); with the plain device-side copies (TD_COMPACT_EGRESS=0), with a run table too small for any read
+    (TD_RLE_CAP=1: every batch takes the fall-back to the labels as they are) and with page-locked input (the keep bits cannot be
+    used: the caller may have refilled the buffer) the bytes are the same, for base codes and for sequence text."""
+    from tagdust_amd import RESULT_DTYPE
+    from tagdust_amd.lib import PinnedArray
+    from conftest import golden_window
+    g = load_golden(name)
+    n = int(g["n_reads"])
+    offs = np.ascontiguousarray(g["offs"], np.int64)
+    seq = np.ascontiguousarray(g["seq"], np.uint8)
+    text = np.frombuffer(b"ACGTN", np.uint8)[seq]
+    outs = {}
+    for label, env, ascii_, pinned in (("compact", {}, False, False), ("plain", {"TD_COMPACT_EGRESS": "0"}, False, False),
+                                       ("overflow", {"TD_RLE_CAP": "1"}, False, False), ("text", {}, True, False), ("pinned", {}, False, True)):
+        for k in ("TD_COMPACT_EGRESS", "TD_RLE_CAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = _ctx(g, 1)
+        pin = PinnedArray((len(seq),), np.uint8) if pinned else None
+        try:
+            c.set_window(*(golden_window(g) or (-1, -1)))
+            src = text if ascii_ else seq
+            if pin is not None:
+                pin.array[:] = src
+                src = pin.array
+            res = np.zeros(n, RESULT_DTYPE); lab = np.full(int(offs[-1]) + n, 99, np.int8); sq = np.full(int(offs[-1]), 99, np.uint8)
+            c.wait(c.submit(src, offs, res=res, labels=lab, seq_out=sq, ascii=ascii_))
+            outs[label] = (res.tobytes(), lab.copy(), sq.copy())
+            # the synchronous calls go the same way
+            if ascii_:
+                c.upload_batch_ascii(text, offs)
+            else:
+                c.upload_batch(seq, offs)
+            c.run()
+            r2, l2, s2 = c.download()
+            assert r2.tobytes() == outs[label][0] and np.array_equal(l2, lab) and np.array_equal(s2, sq)
+        finally:
+            c.close()
+            if pin is not None:
+                pin.free()
+    assert np.array_equal(outs["compact"][1], g["labels"]) and np.array_equal(outs["compact"][2], g["seq_after"])
+    for k in ("plain", "overflow", "text", "pinned"):
+        assert outs[k][0] == outs["compact"][0] and np.array_equal(outs[k][1], outs["compact"][1]) and np.array_equal(outs[k][2], outs["compact"][2]), k

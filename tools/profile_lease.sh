@@ -38,5 +38,9 @@ run pmc2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_
 run pmc3 --pmc SQ_INSTS_FLAT SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT GRBM_GUI_ACTIVE
 export TD_OVERLAP=1
 run trace_ov --kernel-trace
+# what roofline.kernel_ms is: isolated launches on a resident batch, nothing else on the device -- traced by itself, so that
+# rocprofv3's own duration of the dominant kernel can be held against the HIP-event figure of the bench line
+PROF_ARGS="--workload $WL --reads $READS --isolated 20 --warmup 0 --check 0"
+run trace_iso --kernel-trace --stats
 python3 tools/summarize_lease.py $OUT $TAG $WL $READS
 ls $P

@@ -74,6 +74,17 @@ def main():
         res["kernel_trace_overlapping_launches"] = {"dispatches": len(d2), "avg_ms": sum(d2) / len(d2), "min_ms": min(d2), "max_ms": max(d2),
                                                      "avg_start_to_start_ms": (starts[-1] - starts[0]) / 1e6 / (len(starts) - 1),
                                                      "avg_overlap_with_previous_ms": sum(max(0, int(ko[i - 1]["End_Timestamp"]) - starts[i]) for i in range(1, len(ko))) / 1e6 / (len(ko) - 1)}
+    ki = [r for r in rows(os.path.join(out, "trace_iso", "**", "*kernel_trace.csv")) if kname in r.get("Kernel_Name", "")]
+    ki.sort(key=lambda r: int(r["Start_Timestamp"]))
+    if len(ki) > 20:
+        ki = ki[-20:]               # (the first launch of that run is its warm-up)
+    if ki:
+        d3 = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in ki]
+        res["kernel_trace_isolated_launches"] = {"dispatches": len(d3), "avg_ms": sum(d3) / len(d3), "min_ms": min(d3), "max_ms": max(d3),
+                                                  "what": "bench.py --isolated 20 under --kernel-trace: launches on a resident batch with nothing else on the device -- "
+                                                          "the quantity roofline.kernel_ms of the bench line measures with HIP events"}
+        for f in glob.glob(os.path.join(out, "trace_iso", "**", "*kernel_stats.csv"), recursive=True):
+            shutil.copy(f, os.path.join(P, tag + sfx + "_kernel_stats_isolated.csv"))
     for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(P, tag + sfx + "_kernel_stats.csv"))
     pmc = {}
@@ -96,7 +107,8 @@ def main():
         res["hbm"] = {"fetch_bytes_corrected_x2": f, "write_bytes": w, "bytes_per_launch": f + w, "bytes_per_read": (f + w) / n,
                       "tb_per_s_at_traced_kernel_ms": (f + w) / (k_ms * 1e-3) / 1e12, "frac_of_8tb_peak": (f + w) / (k_ms * 1e-3) / 8e12}
         rec = {"round": tag, "kernel": kname, "workload": workload, "reads_per_launch": n, "hbm_bytes_per_launch": f + w,
-               "fetch_bytes_corrected_x2": f, "write_bytes": w, "kernel_ms_same_lease": k_ms, "head": res["head"],
+               "fetch_bytes_corrected_x2": f, "write_bytes": w, "kernel_ms_same_lease": k_ms,
+               "kernel_ms_isolated_traced": res.get("kernel_trace_isolated_launches", {}).get("avg_ms"), "head": res["head"],
                "kernel_source_sha16": res["kernel_source_sha16"], "collected": res["collected"],
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of tools/profile_lease.sh; KiB -> bytes; "
                          "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); SQ_* sums per "
@@ -136,7 +148,7 @@ def main():
                           "valu_insts_per_read": p.get("SQ_INSTS_VALU", 0) / n, "lds_insts_per_read": p.get("SQ_INSTS_LDS", 0) / n,
                           "vmem_rd_insts_per_read": p.get("SQ_INSTS_VMEM_RD", 0) / n, "vmem_wr_insts_per_read": p.get("SQ_INSTS_VMEM_WR", 0) / n}
     json.dump(res, open(os.path.join(P, tag + sfx + "_td_spec_kernel_summary.json"), "w"), indent=1)
-    print(json.dumps({k: res.get(k) for k in ("bench_line_same_lease", "kernel_trace", "kernel_trace_overlapping_launches", "hbm", "derived")}, indent=1))
+    print(json.dumps({k: res.get(k) for k in ("bench_line_same_lease", "kernel_trace", "kernel_trace_isolated_launches", "kernel_trace_overlapping_launches", "hbm", "derived")}, indent=1))
 
 
 if __name__ == "__main__":
