@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <condition_variable>
 #include <deque>
@@ -94,6 +95,8 @@ struct TdSlot {
 	// compact egress: what the host rebuilds the rewritten sequences and the labels from (slot_fetch_begin)
 	uint32_t* d_keepo = nullptr;   size_t cap_keepo = 0;
 	uint32_t* d_rle = nullptr;     size_t cap_rle = 0;     // (+ one word behind the runs: the overflow flag)
+	uint32_t* d_runs = nullptr;    size_t cap_runs = 0;    // label runs in device order, left by the specialised kernel (+ the overflow flag)
+	int32_t runs_cap = 0;          // entries per read in d_runs (0: the last launch left none)
 	uint32_t* h_keepo = nullptr;   size_t cap_h_keepo = 0;
 	uint32_t* h_rle = nullptr;     size_t cap_h_rle = 0;
 	bool use_keep = false, use_rle = false;
@@ -791,7 +794,7 @@ static int slot_events(td_ctx* c, TdSlot& s)
 static void slot_release(TdSlot& s)
 {
 	void* dev[] = { s.d_raw, s.d_offs, s.d_read_at, s.d_keys, s.d_vals, s.d_sort_tmp, s.d_packed, s.d_lens, s.d_art_left,
-	                s.d_out, s.d_res, s.d_seq, s.d_lab, s.d_keepo, s.d_rle };
+	                s.d_out, s.d_res, s.d_seq, s.d_lab, s.d_keepo, s.d_rle, s.d_runs };
 	for (void* p : dev) if (p) (void)hipFree(p);
 	void* pinned[] = { s.h_raw, s.h_offs, s.h_res, s.h_seq, s.h_lab, s.h_keepo, s.h_rle };
 	for (void* p : pinned) if (p) (void)hipHostFree(p);
@@ -1038,6 +1041,14 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 	return TD_OK;
 }
 
+// entries of a read's label-run table: a path visits one label per segment (+ the zeros behind a window, + one to spare)
+static int rle_capacity(const td_ctx* c)
+{
+	int cap = c->hdr.S + 2 < c->hdr.H ? c->hdr.S + 2 : c->hdr.H;
+	if (const char* e = getenv("TD_RLE_CAP")) { const int v = atoi(e); if (v >= 1 && v <= 127) cap = v; }   // tests: force the overflow route
+	return cap;
+}
+
 // the decode kernel over a staged slot
 static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 {
@@ -1095,6 +1106,15 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 		sa.ws = ka.ws; sa.lay = s.slay;
 		sa.lmax = s.n_big > 0 ? s.lmax_small : s.lmax;
 		sa.n_big = s.n_big; sa.lmax_big = s.lmax; sa.lay_big = s.slay_big; sa.out_lmax = s.lmax;
+		s.runs_cap = 0;
+		if (mode == TD_MODE_GET_LABEL) {   // the label runs for the compact egress, and the flag that says a read had more of them
+			const int cap = rle_capacity(c);
+			const size_t words = (size_t)s.n_tiles * (size_t)cap * TD_WAVE + 1;
+			if (ensure(c, &s.d_runs, &s.cap_runs, words * 4) != TD_OK) return TD_FAIL;
+			HIPCHK(c, hipMemsetAsync(s.d_runs + words - 1, 0, 4, s.cs));
+			sa.out_runs = s.d_runs; sa.rle_overflow = (int32_t*)(s.d_runs + words - 1); sa.rle_cap = cap;
+			s.runs_cap = cap;
+		}
 		sa.prune = c->d_prune; sa.prune_stride = c->prune_stride;
 		sa.tile_next = s.wsi ? c->d_tile_next2 : c->d_tile_next;
 		size_t sz = sizeof sa;
@@ -1129,7 +1149,12 @@ static int slot_issue_copies(td_ctx* c, TdSlot& s, hipStream_t down)
 		else HIPCHK(c, hipMemcpyAsync(s.seq_direct ? (void*)s.u_seq : (void*)s.h_seq, s.d_seq, seq_bytes, hipMemcpyDeviceToHost, down));
 	}
 	if (s.u_labels) {
-		if (s.use_rle) HIPCHK(c, hipMemcpyAsync(s.h_rle, s.d_rle, ((size_t)n * (size_t)s.rle_cap + 1) * 4, hipMemcpyDeviceToHost, down));
+		if (s.use_rle) {
+			HIPCHK(c, hipMemcpyAsync(s.h_rle, s.d_rle, ((size_t)n * (size_t)s.rle_cap + 1) * 4, hipMemcpyDeviceToHost, down));
+			s.h_rle[(size_t)n * (size_t)s.rle_cap + 1] = 0;   // ... and the decode kernel's own overflow flag behind the finish kernel's
+			if (s.runs_cap > 0)
+				HIPCHK(c, hipMemcpyAsync(s.h_rle + (size_t)n * (size_t)s.rle_cap + 1, s.d_runs + (size_t)s.n_tiles * (size_t)s.runs_cap * TD_WAVE, 4, hipMemcpyDeviceToHost, down));
+		}
 		else HIPCHK(c, hipMemcpyAsync(s.lab_direct ? (void*)s.u_labels : (void*)s.h_lab, s.d_lab, lab_bytes, hipMemcpyDeviceToHost, down));
 	}
 	HIPCHK(c, hipEventRecord(s.ev_down, down));
@@ -1153,15 +1178,14 @@ static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* l
 	const bool compact = !(getenv("TD_COMPACT_EGRESS") && atoi(getenv("TD_COMPACT_EGRESS")) == 0);
 	s.use_keep = compact && seq_out && seq_bytes && !s.raw_direct && s.h_raw;
 	s.use_rle = compact && labels;
-	s.rle_cap = c->hdr.S + 2 < c->hdr.H ? c->hdr.S + 2 : c->hdr.H;      // runs <= labels visited; a path visits one label per segment
-	if (const char* e = getenv("TD_RLE_CAP")) { const int v = atoi(e); if (v >= 1 && v <= 127) s.rle_cap = v; }   // tests: force the overflow route
+	s.rle_cap = s.runs_cap > 0 ? s.runs_cap : rle_capacity(c);
 	if (res && ensure(c, &s.d_res, &s.cap_res, res_bytes) != TD_OK) return TD_FAIL;
 	if (seq_out && !s.use_keep && ensure(c, &s.d_seq, &s.cap_seq, seq_bytes) != TD_OK) return TD_FAIL;
 	if (labels && !s.use_rle && ensure(c, &s.d_lab, &s.cap_lab, lab_bytes) != TD_OK) return TD_FAIL;
 	if (res && !(s.res_direct = is_pinned(res)) && ensure_pinned(c, &s.h_res, &s.cap_h_res, res_bytes) != TD_OK) return TD_FAIL;
 	if (seq_out && !s.use_keep && !(s.seq_direct = is_pinned(seq_out)) && ensure_pinned(c, &s.h_seq, &s.cap_h_seq, seq_bytes) != TD_OK) return TD_FAIL;
 	if (labels && !s.use_rle && !(s.lab_direct = is_pinned(labels)) && ensure_pinned(c, &s.h_lab, &s.cap_h_lab, lab_bytes) != TD_OK) return TD_FAIL;
-	const size_t keepo_bytes = (size_t)n * (size_t)s.nw1 * 4, rle_bytes = ((size_t)n * (size_t)s.rle_cap + 1) * 4;
+	const size_t keepo_bytes = (size_t)n * (size_t)s.nw1 * 4, rle_bytes = ((size_t)n * (size_t)s.rle_cap + 2) * 4;
 	if (s.use_keep && (ensure(c, &s.d_keepo, &s.cap_keepo, keepo_bytes) != TD_OK || ensure_pinned(c, &s.h_keepo, &s.cap_h_keepo, keepo_bytes) != TD_OK)) return TD_FAIL;
 	if (s.use_rle) {
 		if (ensure(c, &s.d_rle, &s.cap_rle, rle_bytes) != TD_OK || ensure_pinned(c, &s.h_rle, &s.cap_h_rle, rle_bytes) != TD_OK) return TD_FAIL;
@@ -1173,6 +1197,7 @@ static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* l
 	s.sb.keep_out = s.use_keep ? s.d_keepo : nullptr;
 	s.sb.rle_out = s.use_rle ? s.d_rle : nullptr;
 	s.sb.rle_cap = s.rle_cap;
+	s.sb.runs = (s.use_rle && s.runs_cap > 0) ? s.d_runs : nullptr;
 	s.sb.rle_overflow = s.use_rle ? (int32_t*)(s.d_rle + (size_t)n * (size_t)s.rle_cap) : nullptr;
 	if (s.fin != s.cs) HIPCHK(c, hipStreamWaitEvent(s.fin, s.ev_k1, 0));
 	HIPCHK(c, td_stage_finish(s.sb, s.fin));
@@ -1182,16 +1207,29 @@ static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* l
 	return TD_OK;
 }
 
+static double wall_ms()
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+
 static int slot_fetch_end(td_ctx* c, TdSlot& s)
 {
 	if (s.n_reads == 0 || !s.finished) return TD_OK;
+	const bool dbg = getenv("TD_DEBUG_WAIT") != nullptr;
+	const double t0 = dbg ? wall_ms() : 0.0;
+	double t1 = t0;
 	if (s.copies_deferred) {
 		HIPCHK(c, hipEventSynchronize(s.ev_done));
+		t1 = dbg ? wall_ms() : 0.0;
 		if (slot_issue_copies(c, s, c->s_down) != TD_OK) return TD_FAIL;
 	}
 	HIPCHK(c, hipEventSynchronize(s.ev_down));
+	const double t2 = dbg ? wall_ms() : 0.0;
+	struct Rep { bool on; double t0, t1, t2; ~Rep() { if (on) fprintf(stderr, "td_wait: device %.2f ms, download %.2f ms, host %.2f ms\n", t1 - t0, t2 - t1, wall_ms() - t2); } } rep_{ dbg, t0, t1, t2 };
 	const int64_t n = s.n_reads;
-	if (s.use_rle && s.u_labels && s.h_rle[(size_t)n * (size_t)s.rle_cap] != 0) {
+	if (s.use_rle && s.u_labels && (s.h_rle[(size_t)n * (size_t)s.rle_cap] != 0 || s.h_rle[(size_t)n * (size_t)s.rle_cap + 1] != 0)) {
 		// a read with more label runs than the table holds (a model whose labels are not one per segment): the labels as they are
 		const size_t lab_bytes = (size_t)(s.n_bases + n);
 		if (ensure(c, &s.d_lab, &s.cap_lab, lab_bytes) != TD_OK) return TD_FAIL;

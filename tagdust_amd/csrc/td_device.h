@@ -159,4 +159,9 @@ struct TdSpecArgs {
 	int32_t n_big, lmax_big;
 	int32_t out_lmax;                  // stride of out_labels (the batch's longest read), whatever geometry a slot has
 	TdSpecLayout lay_big;
+	// the runs of every read's labels[0..len] -- (run length << 8) | label, at most rle_cap per read, unused entries 0 -- for the
+	// compact egress (td_api.hip): [n_tiles][rle_cap][64]; *rle_overflow is set when a read has more runs.  nullptr: not wanted
+	uint32_t* __restrict__ out_runs;
+	int32_t*  __restrict__ rle_overflow;
+	int32_t rle_cap;
 };

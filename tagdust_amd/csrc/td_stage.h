@@ -29,6 +29,7 @@ struct TdStageBatch {
 	int64_t   soa_stride;
 	const uint32_t* keep;     // [n_tiles][nw1][64]
 	const int8_t*  labels;    // [n_tiles][lmax + 1][64]
+	const uint32_t* runs;     // [n_tiles][rle_cap][64] label runs as the specialised kernel leaves them, or nullptr (then rle_out is scanned from labels)
 	// results in the caller's order (any may be nullptr)
 	uint8_t* res;             // [n] td_read_result (32 B)
 	uint8_t* seq_out;         // [offs[n]]

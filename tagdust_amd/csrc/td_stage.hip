@@ -167,7 +167,12 @@ __global__ __launch_bounds__(STAGE_BLOCK) void td_finish_kernel(const TdStageBat
 			const uint32_t* kw = b.keep + (int64_t)tile * b.nw1 * TD_WAVE;
 			for (int w = 0; w < b.nw1; w++) b.keep_out[i * b.nw1 + w] = kw[w * TD_WAVE + lane];
 		}
-		if (b.rle_out) {
+		if (b.rle_out && b.runs) {      // the decode kernel left the runs: into the caller's order
+			if (k < b.n_reads) {
+				const uint32_t* rs = b.runs + (int64_t)tile * b.rle_cap * TD_WAVE + lane;
+				for (int j = 0; j < b.rle_cap; j++) b.rle_out[i * b.rle_cap + j] = rs[j * TD_WAVE];
+			}
+		} else if (b.rle_out) {
 			// the label path of a read is a handful of runs (it moves through the segments in order): (length, label) pairs
 			const int8_t* lb = b.labels + (int64_t)tile * (b.lmax + 1) * TD_WAVE;
 			uint32_t* dst = (k < b.n_reads) ? b.rle_out + i * b.rle_cap : nullptr;
