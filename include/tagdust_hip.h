@@ -140,6 +140,10 @@ int64_t td_spec_source(const td_model_desc* model, char* buf, int64_t cap);
  * backward bound per bases to go, the two check thresholds of the adjoining read segment; once for each end); *z = the
  * zero-posterior margin.  No GPU needed; for inspection and tests. */
 int td_spec_prune_info(const td_model_desc* model, int32_t lcap, float* tab, float* z, int32_t* n_seg, int32_t* sfx_first);
+/* The impulse-response tables the restarted sweeps of the specialised kernel start from: tab[8][lcap + 8]
+ * = leading segments 0..3, then the first four trailing segments; *restart = 1 when the kernel compiled for this model restarts
+ * its far sweeps (big leading segments; TD_SPEC_RESTART=0 / 1 forces it).  No GPU needed; for inspection and tests. */
+int td_spec_restart_info(const td_model_desc* model, int32_t lcap, float* tab, int32_t* restart);
 /* -ref artifact filter, match_to_reference() src/barcode_hmm.c:2478-2583 (runs between extraction and DUST in
  * TD_MODE_GET_LABEL): string / s_index[n_seq+1] are struct fasta's fields as read_fasta() leaves them (io.c:1912-2001:
  * per sequence one 'X' byte followed by the base codes); filter_error = param->filter_error (-fe);

@@ -92,6 +92,23 @@ def bound_margins(model, seqs, offs, info):
     return out
 
 
+def restart_margins(model, seqs, offs, n_seg, sfx_first, gq, gf):
+    """Smallest margins by which the start of the device kernel's restarted sweeps (tagdust_amd.lib.spec_restart_info()) dominates
+    the backward values of the leading / the forward values of the trailing segments the oracle computes: [backward, forward]."""
+    L = lib()
+    L.tdo_restart_margins.restype = C.c_int
+    L.tdo_restart_margins.argtypes = [C.POINTER(_Model), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.int64)
+    tab = np.ascontiguousarray(np.concatenate([gq, gf]), dtype=np.float32)
+    out = np.zeros(2, np.float64)
+    rc = L.tdo_restart_margins(C.byref(model.c), seqs.ctypes.data, offs.ctypes.data, len(offs) - 1, int(n_seg), int(sfx_first),
+                               tab.ctypes.data, tab.shape[1], out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("tdo_restart_margins failed (%d)" % rc)
+    return out
+
+
 def logsum_table():
     p = lib().tdo_logsum_table()
     return np.ctypeslib.as_array(p, shape=(16000,)).copy()

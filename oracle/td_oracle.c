@@ -732,6 +732,65 @@ int tdo_bound_margins(const tdo_model* m, const uint8_t* seqs, const int64_t* of
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * The same for the start of the device kernel's restarted sweeps (td_spec_kernel.inc "Restarted sweeps"): gq[j] / gf[t] are the
+ * host's impulse-response tables (tagdust_amd.lib.spec_restart_info: leading segments 0..3, then the first four trailing
+ * segments, `stride` floats each).  For every read, every position t and every leading segment j the kernel may start its
+ * upper ends at  max_k (gq_j[k] + SB_nseg[t + 1 + k]) + log(len - t + 1) + 0.02  -- checked here against every M / I backward
+ * value of that segment at t -- and the mirror image  max_k (gf_j[k] + SF_in[t - k]) + log(t) + 0.02  against the forward
+ * values of the trailing segments.  margins[0] backward, [1] forward: the smallest bound - value met (1e30: nothing to check).
+ * ---------------------------------------------------------------------------------------------- */
+int tdo_restart_margins(const tdo_model* m, const uint8_t* seqs, const int64_t* offs, int64_t n_reads, int n_seg, int sfx_first,
+                        const float* tab, int stride, double* margins)
+{
+	int max_len = 1;
+	for (int64_t r = 0; r < n_reads; r++) if (offs[r + 1] - offs[r] > max_len) max_len = (int)(offs[r + 1] - offs[r]);
+	if (max_len + 2 > stride || n_seg < 0 || n_seg >= m->S || sfx_first < 1 || sfx_first > m->S) return -1;
+	tdo_workspace* ws = tdo_workspace_new(m, max_len);
+	if (!ws) return -1;
+	int8_t* labels = (int8_t*)malloc((size_t)max_len + 2);
+	margins[0] = margins[1] = 1.0e30;
+	const int st = ws->stride;
+	for (int64_t r = 0; r < n_reads; r++) {
+		const uint8_t* seq = seqs + offs[r];
+		const int len = (int)(offs[r + 1] - offs[r]);
+		if (len < 1) continue;
+		float f, rs, bp;
+		const float b = tdo_backward(m, ws, seq, len);
+		if (!(b > NEG_INF)) continue;
+		tdo_forward_decode(m, ws, seq, len, b, &f, &rs, &bp, labels);
+		for (int j = 0; j < n_seg && j < 4; j++) {
+			const float* gq = tab + (size_t)j * stride;
+			const float* Q = ws->SB + (size_t)n_seg * st;
+			for (int t = 1; t <= len; t++) {
+				float hi = NEG_INF;
+				for (int k = 0; t + 1 + k <= len + 1; k++) { const float v = gq[k] + Q[t + 1 + k]; if (v > hi) hi = v; }
+				hi = hi + (logf((float)(len - t + 1)) + 0.02f);
+				for (int c = m->col_off[j]; c < m->col_off[j] + m->n_hmm[j] * m->n_col[j]; c++) {
+					const float vb[2] = { ws->MB[c * st + t], ws->IB[c * st + t] };
+					for (int k = 0; k < 2; k++) if (vb[k] > NEG_INF && (double)hi - vb[k] < margins[0]) margins[0] = (double)hi - vb[k];
+				}
+			}
+		}
+		for (int j = sfx_first; j < m->S && j - sfx_first < 4; j++) {
+			const float* gf = tab + (size_t)(4 + j - sfx_first) * stride;
+			const float* P = ws->SF + (size_t)(sfx_first - 1) * st;
+			for (int t = 1; t <= len; t++) {
+				float hi = NEG_INF;
+				for (int k = 1; k <= t; k++) { const float v = gf[k] + P[t - k]; if (v > hi) hi = v; }
+				hi = hi + (logf((float)t) + 0.02f);
+				for (int c = m->col_off[j]; c < m->col_off[j] + m->n_hmm[j] * m->n_col[j]; c++) {
+					const float vf[2] = { ws->MF[c * st + t], ws->IF[c * st + t] };
+					for (int k = 0; k < 2; k++) if (vf[k] > NEG_INF && (double)hi - vf[k] < margins[1]) margins[1] = (double)hi - vf[k];
+				}
+			}
+		}
+	}
+	free(labels);
+	tdo_workspace_free(ws);
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * run_pHMM(MODE_GET_LABEL) analogue, barcode_hmm.c:1895-2029
  * ---------------------------------------------------------------------------------------------- */
 struct batch_job {

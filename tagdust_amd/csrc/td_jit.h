@@ -15,7 +15,9 @@ int td_spec_first_labels(const td_model_desc* m);   /* labels whose posteriors t
 int td_spec_prune_segs(const td_model_desc* m);    /* leading segments the forward sweep may cut short (0: none), td_spec_kernel.inc "Position pruning" */
 int td_spec_prune_sfx(const td_model_desc* m);     /* first trailing segment the backward sweep may cut short (S: none) */
 float td_spec_prune_z(const td_model_desc* m, int n_seg, int sfx_first);
-#define TD_PRUNE_TABLES 8
+#define TD_PRUNE_TABLES 16   /* 8 position-pruning tables, then up to 4 + 4 impulse-response tables of the restarted sweeps */
+#define TD_PRUNE_RESTART_MAX 4   /* leading / trailing segments a restart can bridge */
+int td_spec_restart(const td_model_desc* m);   /* 1: the specialised kernel restarts the far sweeps of the pruned segments (TDS_RESTART) */
 void td_spec_prune_tables(const td_model_desc* m, int n_seg, int sfx_first, int lcap, int stride, std::vector<float>& tab);
 int td_spec_lsum_oob(void);      /* 1: clamp-free logsum (LDS out-of-range reads as 0), see td_spec_kernel.inc */
 std::string td_spec_model_section(const td_model_desc* m, int lsum_oob = -1, int window = 0);   /* lsum_oob < 0: td_spec_lsum_oob(); window: -start/-end support compiled in */

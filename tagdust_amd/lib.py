@@ -20,7 +20,7 @@ NUM_DIAG_COUNTERS = 64
 ABI_SYMBOLS = [
     "td_ctx_create", "td_ctx_destroy", "td_last_error", "td_logsum_table", "td_model_upload", "td_set_params",
     "td_batch_upload", "td_batch_upload_ascii", "td_run", "td_sync", "td_batch_download", "td_counts_reset",
-    "td_counts_get", "td_diag_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_timeline_origin", "td_last_kernel_times", "td_batch_info", "td_set_option", "td_get_option", "td_set_artifacts", "td_spec_source", "td_spec_prune_info",
+    "td_counts_get", "td_diag_get", "td_counts_device_ptr", "td_last_kernel_ms", "td_timeline_origin", "td_last_kernel_times", "td_batch_info", "td_set_option", "td_get_option", "td_set_artifacts", "td_spec_source", "td_spec_prune_info", "td_spec_restart_info",
     "td_submit", "td_wait", "td_host_alloc", "td_host_free", "td_set_batch_window", "td_set_window", "td_arch_scores",
 ]
 MULTI_ABI_SYMBOLS = ["td_shard_bounds", "td_count_outcomes", "td_multi_create", "td_multi_destroy", "td_multi_last_error",
@@ -473,6 +473,20 @@ def spec_prune_info(md, lcap):
     for k, name in enumerate(("fb", "bwb", "wa", "wb", "fbs", "bws", "wc", "wd")):
         out[name] = t[k]
     return out
+
+
+def spec_restart_info(md, lcap):
+    """Impulse-response tables of the restarted sweeps for this model: (gq [4, lcap + 8] leading segments, gf [4, lcap + 8]
+    trailing segments, restart flag)."""
+    lib = load_library()
+    d, keep = make_model_desc(md)
+    tab = np.zeros(8 * (lcap + 8), np.float32)
+    r = C.c_int32(0)
+    lib.td_spec_restart_info.argtypes = [C.POINTER(_ModelDesc), C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]
+    if lib.td_spec_restart_info(C.byref(d), int(lcap), tab.ctypes.data, C.byref(r)) != 0:
+        raise RuntimeError("td_spec_restart_info failed")
+    t = tab.reshape(8, lcap + 8)
+    return t[:4], t[4:], int(r.value)
 
 
 class TagdustHip:

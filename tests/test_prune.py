@@ -23,6 +23,29 @@ def _margins(md, seq, offs):
     return info, pyoracle.bound_margins(pyoracle.OracleModel(md), seq, offs, info)
 
 
+def _restart_margins(md, seq, offs):
+    from oracle import pyoracle
+    from tagdust_amd import lib as tdlib
+    lcap = int(np.diff(offs).max()) + 2
+    info = tdlib.spec_prune_info(md, lcap)
+    if info["n_seg"] == 0 and info["sfx_first"] == info["S"]:
+        return None
+    gq, gf, _ = tdlib.spec_restart_info(md, lcap)
+    return pyoracle.restart_margins(pyoracle.OracleModel(md), seq, offs, info["n_seg"], info["sfx_first"], gq, gf)
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_restart_bounds_dominate_reference_values(name):
+    """Where a restarted sweep starts its upper ends -- max_k (impulse response[k] + the exact silent row k positions on) + log of
+    the number of terms -- lies above every backward value of the leading and every forward value of the trailing segments, for
+    every read and every position of every reference fixture.  (A start below a true value would make the interval close on a
+    wrong number: this is the test the exactness of the restarts rests on.)"""
+    g = load_golden(name)
+    mg = _restart_margins(g, g["seq"], g["offs"])
+    if mg is not None:
+        assert mg.min() > 0.0, (name, mg)
+
+
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_bounds_dominate_reference_values(name):
     """fb[i] >= M/I_forward, bwb[len - i] >= M/I_backward of the pruned segments, wa[i] - 15.75 >= the read segment's entry
@@ -72,6 +95,9 @@ def test_bounds_dominate_on_random_architectures(seed):
     info, mg = _margins(md, seq, offs)
     if mg is not None:
         assert mg.min() > 0.0, (segs, mg)
+    rm = _restart_margins(md, seq, offs)      # ... and so do the bounds the restarted sweeps start from
+    if rm is not None:
+        assert rm.min() > 0.0, (segs, rm)
 
 
 def test_model_section_states_the_pruned_segments():
@@ -291,22 +317,29 @@ def test_reads_beyond_the_bound_tables_decode_densely():
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload,n", [("c3", 1 << 15), ("c2", 1 << 15), ("c5", 1 << 13)], ids=["config3", "config2", "config5"])
 def test_restarted_sweeps_are_exact_or_fall_back(workload, n):
-    """TDS_RESTART (off by default, td_spec_kernel.inc "Restarted sweeps"): the leading segments' backward sweep and the trailing
-    segments' forward sweep start W positions before the first position their values are used at, from the interval
-    [-inf, host bound], and hand over to the plain sweep once every interval has closed.  With W = 40 every bridge closes and
-    the outputs are those of the dense sweeps, bit for bit; with W = 2 none can close, every tile takes the dense second pass,
-    and the outputs are still the same."""
-    dense = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_STATS": "0"})
-    on = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_STATS": "1", "TD_SPEC_EXTRA_OPTS": "-DTDS_RESTART=1 -DTDS_RESTART_W=40"})
+    """TDS_RESTART (td_spec_kernel.inc "Restarted sweeps"): the leading segments' backward sweep and -- with TDS_RESTART_FWD -- the
+    trailing segments' forward sweep start W positions before the first position their values are used at, from an interval
+    whose upper end is the host's relative bound, and hand over to the plain sweep once every interval has closed.  Forced on
+    with W = 40 every bridge closes and the outputs are those of the dense sweeps, bit for bit; with W = 2 none can close, every
+    tile takes the dense second pass, and the outputs are still the same.  Config 5 restarts by default (big leading segments)."""
+    dense = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_RESTART": "0", "TD_SPEC_PRUNE_STATS": "0"})
+    on = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_RESTART": "1", "TD_SPEC_PRUNE_STATS": "1", "TD_SPEC_EXTRA_OPTS": "-DTDS_RESTART_W=40 -DTDS_RESTART_FWD=1"})
     assert _same(dense, on)
     d = on[3]
     tiles = (n + 63) // 64
     assert d[206 - 192] == tiles and d[207 - 192] == 0                     # backward: restarted in every tile, none failed
-    assert d[197 - 192] > 0 and 3 < d[196 - 192] / d[197 - 192] < 40       # bridges closed well inside W
+    assert d[197 - 192] > 0 and 3 < d[196 - 192] / d[197 - 192] < 25       # bridges closed well inside W
     if workload != "c2":                                                   # (config 2 has no segment behind its read segment)
         assert d[198 - 192] == tiles and d[199 - 192] == 0                 # forward likewise
     assert d[238 - 192] == 0                                               # no dense second pass
-    short = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_STATS": "1", "TD_SPEC_EXTRA_OPTS": "-DTDS_RESTART=1 -DTDS_RESTART_W=2"})
+    short = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_RESTART": "1", "TD_SPEC_PRUNE_STATS": "1", "TD_SPEC_EXTRA_OPTS": "-DTDS_RESTART_W=2"})
     assert _same(dense, short)
     d = short[3]
     assert d[207 - 192] > 0 and d[238 - 192] == tiles                      # every restarted tile failed to close and was decoded densely
+    default = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_STATS": "1"})
+    assert _same(dense, default)
+    d = default[3]
+    if workload == "c5":
+        assert d[206 - 192] == tiles and d[207 - 192] == 0 and d[238 - 192] == 0     # on by default, every bridge closes
+    else:
+        assert d[206 - 192] == 0                                                      # off for a handful of HMMs
