@@ -51,5 +51,6 @@ for name, (reads, offs) in sets.items():
     same = a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     cnt = out[1][2]
     tiles = max(int(cnt[236 - 192]), 1)
-    print(wl + " %-52s off %7.2f ms  on %7.2f ms (x%.2f)  mean cut %5.1f  mean stop %5.1f  dense tiles %d / %d  identical %s" % (
-        name, out[0][0], out[1][0], out[0][0] / out[1][0], cnt[237 - 192] / tiles, cnt[227 - 192] / tiles, cnt[238 - 192], tiles, same), flush=True)
+    print(wl + " %-52s off %7.2f ms  on %7.2f ms (x%.2f)  mean cut %5.1f  mean stop %5.1f  dense tiles %d / %d  restarted %d (bridges failed in %d, mean interval steps %.1f)  identical %s" % (
+        name, out[0][0], out[1][0], out[0][0] / out[1][0], cnt[237 - 192] / tiles, cnt[227 - 192] / tiles, cnt[238 - 192], tiles,
+        cnt[206 - 192], cnt[207 - 192], cnt[196 - 192] / max(int(cnt[197 - 192]), 1), same), flush=True)
