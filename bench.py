@@ -705,6 +705,25 @@ def main():
         }
         extra["kernel_only"] = iso
     close()
+    if args.extras and world > 1:
+        # every rank again with page-locked caller buffers (td_host_alloc): no staging copies on the host at all -- beside the
+        # headline's pageable buffers, so that a host-side limit of the N-GPU run shows up as the difference between the two
+        try:
+            c2, m2, go2, st2, ko2, close2, _ = measure_workload(args.workload, n, 12, 3, dev_index, args.specialize, args.depth, True,
+                                                                 check=0, kernel_only_steps=0, labels=bool(args.labels))
+            c2.sync(); dist.barrier()
+            t1 = time.perf_counter()
+            go2(12, bool(args.labels))
+            c2.sync(); dist.barrier()
+            t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=reduce_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            close2()
+            if rank == 0:
+                extra["pinned_io"] = {"value": n * 12 * world / float(t.item()), "unit": "reads/s", "steps": 12, "host_buffers": "page-locked (td_host_alloc)",
+                                      "note": "all ranks, max over ranks; the headline uses pageable buffers"}
+        except Exception as e:
+            if rank == 0:
+                extra["pinned_io"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and args.extras and world == 1:
         # beside the headline: the same pipeline with page-locked caller buffers, and BASELINE configs[1] / configs[4]
         # (parity-test cases per the contract, timed here so that their rates are on the driver's record)
