@@ -1,0 +1,33 @@
+#include "tagdust_io.h"
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+// stand-ins for the device entry points (the parse-only run never calls them; a "decoding" run here returns zeroed results)
+extern "C" {
+void* td_host_alloc(size_t b) { return malloc(b ? b : 1); }
+void td_host_free(void* p) { free(p); }
+int td_get_option(td_ctx*, const char*, int32_t* v) { *v = 3; return 0; }
+const char* td_last_error(const td_ctx*) { return "stub"; }
+static int64_t g_t = 0;
+int td_submit(td_ctx*, const void*, int32_t, const int64_t* offs, int64_t n, int, td_read_result* res, int8_t*, uint8_t* seq_out, int64_t* ticket)
+{ memset(res, 0, sizeof(td_read_result) * (size_t)n); for (int64_t i = 0; i < n; i++) { res[i].barcode = (int32_t)(i % 3); res[i].fingerprint = -1; res[i].mapq = 12.345f; } memset(seq_out, 1, (size_t)(offs[n] - offs[0])); *ticket = ++g_t; return 0; }
+int td_wait(td_ctx*, int64_t) { return 0; }
+}
+int main(int argc, char** argv)
+{
+	td_stream_stats st;
+	td_stream_opts o = { atoi(argv[2]), atoi(argv[3]), atol(argv[4]) };
+	static char b0[] = "ACGT", b1[] = "TTGA", b2[] = "GGCC", bn[] = "NNNN", rn[] = "N";
+	static char* bs[] = { b0, b1, b2, bn };
+	static char* rs[] = { rn };
+	static td_arch arch;
+	arch.n_segments = 2; arch.type[0] = 'B'; arch.type[1] = 'R'; arch.n_seq[0] = 4; arch.n_seq[1] = 1; arch.seq_len[0] = 4; arch.seq_len[1] = 1;
+	arch.seqs[0] = bs; arch.seqs[1] = rs;
+	td_arch* a = &arch;
+	for (int rep = 0; rep < 2; rep++) {
+		int rc = td_stream_run(argc > 5 ? (td_ctx*)0x1 : nullptr, argv[1], a, "/tmp/td_tsan/out", &o, &st);
+		printf("rc %d reads %lld batches %lld bytes_out %lld fnv %llx\n", rc, (long long)st.n_reads, (long long)st.n_batches, (long long)st.bytes_out, (unsigned long long)st.codes_fnv);
+	}
+	td_stream_release();
+	return 0;
+}
