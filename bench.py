@@ -505,7 +505,7 @@ def bind_rank_to_numa(dev_index, local_rank, local_world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=60, help="timed steps (60 x 2^20 reads = 1.2 s per GPU: the pipeline's fill and drain are one step of them)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=1 << 20, help="reads per step per GPU")
     ap.add_argument("--cpu-sample", type=int, default=200000, help="reads in the CPU baseline sample (0 = skip)")
