@@ -224,11 +224,23 @@ def test_pruning_on_ragged_short_and_dead_reads():
         assert np.array_equal(res[k], ores[k]), k
 
 
+_LONG_SEEDS = list(range(10))
+if os.environ.get("TD_FUZZ_SEEDS"):      # e.g. TD_FUZZ_SEEDS=100:400 for a longer one-off run
+    _a, _b = os.environ["TD_FUZZ_SEEDS"].split(":")
+    _LONG_SEEDS = list(range(int(_a), int(_b)))
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(10))
-def test_random_architectures_with_long_inserts(seed):
+@pytest.mark.parametrize("restart", [None, "1"], ids=["restart-by-size", "restart-forced"])
+@pytest.mark.parametrize("seed", _LONG_SEEDS)
+def test_random_architectures_with_long_inserts(seed, restart, monkeypatch):
     """Random segment lists as in test_parity_gpu, but with inserts of 120-220 bases: every read reaches far beyond the pruning
-    cut and far in front of the trailing segments' stop.  Specialised kernel (pruning on) == oracle, bit for bit."""
+    cut and far in front of the trailing segments' stop.  Specialised kernel (pruning on) == oracle, bit for bit -- also with
+    the restarted sweeps forced on for both ends (TDS_RESTART, TDS_RESTART_FWD: the interval bridges must close on the
+    reference's floats or fail over to the plain sweep, whatever the segments look like)."""
+    if restart:
+        monkeypatch.setenv("TD_SPEC_RESTART", restart)
+        monkeypatch.setenv("TD_SPEC_EXTRA_OPTS", "-DTDS_RESTART_FWD=1")
     from oracle import pyoracle
     from tagdust_amd import TagdustHip
     from tagdust_amd import lib as tdlib
