@@ -25,6 +25,8 @@ def check(name="c3_b6_s_r_p", keep=False, outdir="/tmp/td_spec"):
            "--cuda-device-only", "-c", path, "-o", os.path.join(outdir, name + ".o"), "-Rpass-analysis=kernel-resource-usage"]
     if os.environ.get("TD_SPEC_SLP", "0") == "0":
         cmd += ["-fno-slp-vectorize"]      # as td_jit.hip compiles it
+    if os.environ.get("TD_SPEC_MLICM", "0") == "0":
+        cmd += ["-mllvm", "-disable-machine-licm"]
     cmd += os.environ.get("TD_SPEC_EXTRA_OPTS", "").split()
     if keep:
         cmd += ["-save-temps=obj"]
