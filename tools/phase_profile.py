@@ -21,10 +21,11 @@ for wl in sys.argv[1:] or ["c3", "c2"]:
     d = c.diag().astype(np.float64)
     t = d[240 - 192:252 - 192]
     print(wl, "kernel %.2f ms" % c.last_kernel_ms())
+    total = t.sum() + (d[208 - 192:224 - 192].sum() if LEVEL == 2 else 0.0)
     for k, nm in enumerate(NAMES):
         if t[k]:
-            print("   %-20s %5.1f %%" % (nm, 100 * t[k] / t.sum()))
+            print("   %-20s %5.1f %%" % (nm, 100 * t[k] / total))
     if LEVEL == 2:   # the sweeps' shares above then hold only what is left outside the segments
         for nm, o in (("backward", 208 - 192), ("forward", 216 - 192)):
-            print("   %s by segment: %s" % (nm, "  ".join("%d: %.1f %%" % (j, 100 * d[o + j] / t.sum()) for j in range(8) if d[o + j])))
+            print("   %s by segment: %s" % (nm, "  ".join("%d: %.1f %%" % (j, 100 * d[o + j] / total) for j in range(8) if d[o + j])))
     c.close()
