@@ -28,6 +28,9 @@ import os
 import sys
 import time
 
+# (as the library does when it is loaded -- see td_want_hw_queues in td_api.hip -- but before torch can initialise the runtime)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))

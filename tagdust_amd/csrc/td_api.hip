@@ -122,6 +122,14 @@ static int default_host_threads()
 }
 
 // The copy threads of one context: started once, reused by every batch (the calling thread takes a share of each copy itself).
+// The pipelined calls keep six streams busy (two compute streams, upload, download and two for the small kernels around the
+// decode).  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, four unless told otherwise; sharing one
+// with a compute stream leaves a copy or a finish kernel queued behind a 20 ms decode launch (measured: 34.8 ms per 2^20-read
+// step against 19.8 with eight queues -- which streams end up sharing depends on the timing of their first use, so it shows on
+// some machines and not on others).  The runtime reads the variable when it initialises, at the process's first HIP call; a
+// value the user has set is left alone.
+__attribute__((constructor)) static void td_want_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 struct CopyPool {
 	struct Job { char* dst; const char* src; size_t bytes; const std::function<void(int64_t, int64_t)>* fn; int64_t lo, hi; };
 	std::vector<std::thread> th;
@@ -1150,10 +1158,10 @@ static int slot_issue_copies(td_ctx* c, TdSlot& s, hipStream_t down)
 	}
 	if (s.u_labels) {
 		if (s.use_rle) {
+			// (the overflow flag travels behind the runs in the same copy -- the finish kernel folded the decode kernel's own flag
+			// into it: a copy of a few bytes is carried out by a blit kernel, which gets no CU while a decode launch holds every
+			// register file and made this wait last as long as that launch: tools/ubench/copy_overlap.cpp)
 			HIPCHK(c, hipMemcpyAsync(s.h_rle, s.d_rle, ((size_t)n * (size_t)s.rle_cap + 1) * 4, hipMemcpyDeviceToHost, down));
-			s.h_rle[(size_t)n * (size_t)s.rle_cap + 1] = 0;   // ... and the decode kernel's own overflow flag behind the finish kernel's
-			if (s.runs_cap > 0)
-				HIPCHK(c, hipMemcpyAsync(s.h_rle + (size_t)n * (size_t)s.rle_cap + 1, s.d_runs + (size_t)s.n_tiles * (size_t)s.runs_cap * TD_WAVE, 4, hipMemcpyDeviceToHost, down));
 		}
 		else HIPCHK(c, hipMemcpyAsync(s.lab_direct ? (void*)s.u_labels : (void*)s.h_lab, s.d_lab, lab_bytes, hipMemcpyDeviceToHost, down));
 	}
@@ -1199,6 +1207,7 @@ static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* l
 	s.sb.rle_cap = s.rle_cap;
 	s.sb.runs = (s.use_rle && s.runs_cap > 0) ? s.d_runs : nullptr;
 	s.sb.rle_overflow = s.use_rle ? (int32_t*)(s.d_rle + (size_t)n * (size_t)s.rle_cap) : nullptr;
+	s.sb.runs_overflow = (s.use_rle && s.runs_cap > 0) ? (const int32_t*)(s.d_runs + (size_t)s.n_tiles * (size_t)s.runs_cap * TD_WAVE) : nullptr;
 	if (s.fin != s.cs) HIPCHK(c, hipStreamWaitEvent(s.fin, s.ev_k1, 0));
 	HIPCHK(c, td_stage_finish(s.sb, s.fin));
 	if (deferred) HIPCHK(c, hipEventRecord(s.ev_done, s.fin));
@@ -1229,7 +1238,7 @@ static int slot_fetch_end(td_ctx* c, TdSlot& s)
 	const double t2 = dbg ? wall_ms() : 0.0;
 	struct Rep { bool on; double t0, t1, t2; ~Rep() { if (on) fprintf(stderr, "td_wait: device %.2f ms, download %.2f ms, host %.2f ms\n", t1 - t0, t2 - t1, wall_ms() - t2); } } rep_{ dbg, t0, t1, t2 };
 	const int64_t n = s.n_reads;
-	if (s.use_rle && s.u_labels && (s.h_rle[(size_t)n * (size_t)s.rle_cap] != 0 || s.h_rle[(size_t)n * (size_t)s.rle_cap + 1] != 0)) {
+	if (s.use_rle && s.u_labels && s.h_rle[(size_t)n * (size_t)s.rle_cap] != 0) {
 		// a read with more label runs than the table holds (a model whose labels are not one per segment): the labels as they are
 		const size_t lab_bytes = (size_t)(s.n_bases + n);
 		if (ensure(c, &s.d_lab, &s.cap_lab, lab_bytes) != TD_OK) return TD_FAIL;
@@ -1260,7 +1269,21 @@ static int slot_fetch_end(td_ctx* c, TdSlot& s)
 						const uint8_t* src = raw + o + p0; uint8_t* dst = out + o + p0;
 						if (w == 0u) { memset(dst, 65, (size_t)e); continue; }
 						if (ascii) { for (int q = 0; q < e; q++) dst[q] = ((w >> q) & 1u) ? lut.t[src[q]] : (uint8_t)65; }
-						else { for (int q = 0; q < e; q++) { const uint8_t cd = src[q] > 4 ? (uint8_t)4 : src[q]; dst[q] = ((w >> q) & 1u) ? cd : (uint8_t)65; } }
+						else {
+							// eight bases per step: the keep bits of the group spread into byte masks, kept bytes taken as they are
+							// (a group holding a code above 4 goes byte by byte)
+							int q = 0;
+							for (; q + 8 <= e; q += 8) {
+								uint64_t v;
+								memcpy(&v, src + q, 8);
+								if (((v + 0x7B7B7B7B7B7B7B7BULL) | v) & 0x8080808080808080ULL) break;
+								uint64_t m = ((uint64_t)((w >> q) & 0xFFu) * 0x0101010101010101ULL) & 0x8040201008040201ULL;
+								m = (((m + 0x7F7F7F7F7F7F7F7FULL) & 0x8080808080808080ULL) >> 7) * 0xFFULL;
+								v = (v & m) | (0x4141414141414141ULL & ~m);
+								memcpy(dst + q, &v, 8);
+							}
+							for (; q < e; q++) { const uint8_t cd = src[q] > 4 ? (uint8_t)4 : src[q]; dst[q] = ((w >> q) & 1u) ? cd : (uint8_t)65; }
+						}
 					}
 				}
 			};
@@ -1274,8 +1297,18 @@ static int slot_fetch_end(td_ctx* c, TdSlot& s)
 			const std::function<void(int64_t, int64_t)> fn = [=](int64_t lo, int64_t hi) {
 				for (int64_t i = lo; i < hi; i++) {
 					int8_t* p = out + offs[i] + i;
+					int8_t* const end = out + offs[i + 1] + i + 1;   // the read's len + 1 labels
 					const uint32_t* r = rl + i * cap;
-					for (int j = 0; j < cap && r[j]; j++) { const size_t len = r[j] >> 8; memset(p, (int)(int8_t)(r[j] & 0xFF), len); p += len; }
+					for (int j = 0; j < cap && r[j]; j++) {
+						// a run in 8-byte stores that may run over into the next run of the same read (written after it), never
+						// past the read's own labels
+						const size_t len = r[j] >> 8;
+						const uint64_t pat = (uint64_t)(r[j] & 0xFF) * 0x0101010101010101ULL;
+						size_t k = 0;
+						for (; k < len && p + k + 8 <= end; k += 8) memcpy(p + k, &pat, 8);
+						for (; k < len; k++) p[k] = (int8_t)(r[j] & 0xFF);
+						p += len;
+					}
 				}
 			};
 			c->pool.ranges(n, c->host_threads, fn);

@@ -39,6 +39,7 @@ struct TdStageBatch {
 	uint32_t* rle_out;        // [n][rle_cap] the runs of ri->labels[0..len]: (run length << 8) | label, unused entries 0
 	int32_t   rle_cap;
 	int32_t*  rle_overflow;   // set to 1 when a read has more than rle_cap runs (the host then asks for labels_out)
+	const int32_t* runs_overflow;   // the decode kernel's own flag of that kind (with runs), folded into rle_overflow: one word to fetch
 };
 
 // bytes of scratch td_stage_sort needs for n reads

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(STAGE_BLOCK) void td_finish_kernel(const TdStageBat
 			for (int w = 0; w < b.nw1; w++) b.keep_out[i * b.nw1 + w] = kw[w * TD_WAVE + lane];
 		}
 		if (b.rle_out && b.runs) {      // the decode kernel left the runs: into the caller's order
+			if (b.runs_overflow && blockIdx.x == 0 && threadIdx.x == 0 && *b.runs_overflow) atomicOr(b.rle_overflow, 1);
 			if (k < b.n_reads) {
 				const uint32_t* rs = b.runs + (int64_t)tile * b.rle_cap * TD_WAVE + lane;
 				for (int j = 0; j < b.rle_cap; j++) b.rle_out[i * b.rle_cap + j] = rs[j * TD_WAVE];

@@ -87,6 +87,7 @@ def load_library():
                 sys.stderr.write("tagdust_amd: %s is older than its sources -- run `python -m tagdust_amd.build`\n" % LIB_PATH)
         except Exception:
             pass
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # read by the HIP runtime at its first call (td_want_hw_queues, td_api.hip)
     lib = C.CDLL(LIB_PATH)
     lib.td_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     lib.td_ctx_destroy.argtypes = [C.c_void_p]
