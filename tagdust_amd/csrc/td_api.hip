@@ -123,11 +123,10 @@ static int default_host_threads()
 
 // The copy threads of one context: started once, reused by every batch (the calling thread takes a share of each copy itself).
 // The pipelined calls keep six streams busy (two compute streams, upload, download and two for the small kernels around the
-// decode).  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, four unless told otherwise; sharing one
-// with a compute stream leaves a copy or a finish kernel queued behind a 20 ms decode launch (measured: 34.8 ms per 2^20-read
-// step against 19.8 with eight queues -- which streams end up sharing depends on the timing of their first use, so it shows on
-// some machines and not on others).  The runtime reads the variable when it initialises, at the process's first HIP call; a
-// value the user has set is left alone.
+// decode).  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, four unless told otherwise: two of the
+// six then share one, and whatever sits behind a 20 ms decode launch in its queue waits for it.  Eight leaves every stream its
+// own queue (measured on one box: 17.6 / 17.6 ms per 2^20-read step against 17.6 / 18.5 with four).  The runtime reads the
+// variable when it initialises, at the process's first HIP call; a value the user has set is left alone.
 __attribute__((constructor)) static void td_want_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 struct CopyPool {
