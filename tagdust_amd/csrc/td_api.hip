@@ -1159,7 +1159,7 @@ static int slot_issue_copies(td_ctx* c, TdSlot& s, hipStream_t down)
 		if (s.use_rle) {
 			// (the overflow flag travels behind the runs in the same copy -- the finish kernel folded the decode kernel's own flag
 			// into it: a copy of a few bytes is carried out by a blit kernel, which gets no CU while a decode launch holds every
-			// register file and made this wait last as long as that launch: tools/ubench/copy_overlap.cpp)
+			// register file and made this wait last as long as that launch: tools/ubench/copy_kinds.cpp)
 			HIPCHK(c, hipMemcpyAsync(s.h_rle, s.d_rle, ((size_t)n * (size_t)s.rle_cap + 1) * 4, hipMemcpyDeviceToHost, down));
 		}
 		else HIPCHK(c, hipMemcpyAsync(s.lab_direct ? (void*)s.u_labels : (void*)s.h_lab, s.d_lab, lab_bytes, hipMemcpyDeviceToHost, down));

@@ -1,7 +1,9 @@
-// copy_overlap: does a device<->host copy issued while a kernel owns every CU proceed beside it (SDMA engines) or behind it
-// (a blit kernel that waits for CU slots)?  Times a 64 MB pinned D2H / H2D copy alone, then under a spin kernel that fills the
-// register files for ~40 ms, then the same with the spin kernel on a stream whose CU mask leaves one CU per XCD free.
-//   hipcc --offload-arch=gfx950 -O2 tools/ubench/copy_overlap.cpp -o /tmp/copy_overlap && /tmp/copy_overlap
+// copy_kinds: does a device<->host copy issued while a kernel owns every CU proceed beside it (SDMA engines) or behind it
+// (a blit kernel that waits for CU slots)?  Times a pinned D2H / H2D copy alone, then under a spin kernel that fills the
+// register files for ~45 ms (four rounds of ~11 ms workgroups), for several kinds of copy: plain and high-priority streams,
+// hipHostMalloc / Portable / hipHostRegister memory, behind an event wait, and small sizes.  A copy that takes ~1.2 ms per
+// 64 MB went through SDMA; one that takes about as long as a round of the spin kernel was a blit kernel waiting for a CU.
+//   hipcc --offload-arch=gfx950 -O2 tools/ubench/copy_kinds.cpp -o /tmp/copy_kinds && /tmp/copy_kinds
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -26,19 +28,10 @@ int main()
 	const size_t bytes = 64u << 20;
 	void *d = nullptr, *h = nullptr; float* sink = nullptr;
 	CK(hipMalloc(&d, bytes)); CK(hipHostMalloc(&h, bytes, hipHostMallocDefault)); CK(hipMalloc((void**)&sink, 4));
-	hipStream_t sk, sc, sm;
+	hipStream_t sk, sc;
 	CK(hipStreamCreateWithFlags(&sk, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sc, hipStreamNonBlocking));
 	hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
 	const int cus = p.multiProcessorCount;
-	// CU masks (bit k = CU k in the runtime's enumeration): all CUs but (a) one in every 32, (b) the first 8, (c) the first 16
-	std::vector<uint32_t> mask((cus + 31) / 32, 0xFFFFFFFFu);
-	for (size_t k = 0; k < mask.size(); k++) mask[k] &= ~1u;
-	CK(hipExtStreamCreateWithCUMask(&sm, (uint32_t)mask.size(), mask.data()));
-	hipStream_t sm8, sm16;
-	std::vector<uint32_t> m8((cus + 31) / 32, 0xFFFFFFFFu), m16((cus + 31) / 32, 0xFFFFFFFFu);
-	m8[0] = 0xFFFFFF00u; m16[0] = 0xFFFF0000u;
-	CK(hipExtStreamCreateWithCUMask(&sm8, (uint32_t)m8.size(), m8.data()));
-	CK(hipExtStreamCreateWithCUMask(&sm16, (uint32_t)m16.size(), m16.data()));
 	const long long cyc = 40LL * 100000;   // wall_clock64 ticks at 100 MHz: ~40 ms
 	auto copy_ms = [&](bool d2h) {
 		const double t0 = now_ms();
