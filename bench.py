@@ -699,7 +699,7 @@ def main():
                          "traffic_gbps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
                          "traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "traffic_source": traffic_note,
-                         "valu": valu_roofline(rec, n, k_ms),
+                         "valu": valu_roofline(rec, n, k_ms, args.workload),
                          "note": "algorithmic bytes are tiny (SURVEY.md 8d: not HBM-bound); the kernel's real HBM traffic is the "
                                  "backward-row spill (traffic_gbps), which no longer binds since the position pruning.  What binds is "
                                  "the compute side: `valu` prices the kernel's VALU wave-instructions (PMC, same kernel source) against "
@@ -770,7 +770,13 @@ VALU_ISSUE_PEAK = 1.229e12   # wave64 VALU instructions per second: 256 CUs x 4 
 VALU_NS_FAST, VALU_NS_SLOW = 1.0, 1.75   # tools/ubench/valu_rate.hip: ns per wave64 instruction per SIMD, the two issue classes of gfx950
 
 
-def valu_roofline(rec, n, k_ms):
+# logsum evaluations of the reference per read that reach the table (the others have a -inf operand), measured
+# there by instrumenting the reference; each costs ~10 lane operations + one LDS look-up in the formulation the survey prices
+ALGORITHMIC_TABLE_LOGSUMS_PER_READ = {"c2": 17.3e3, "c3": 63.2e3, "c5": 527e3}
+LANE_OPS_PER_LOGSUM = 10
+
+
+def valu_roofline(rec, n, k_ms, workload="c3"):
     """Compute-side roofline of the decode kernel from the PMC record of the same kernel source (profiles/traffic.json):
     VALU wave-instructions per launch against the chip's issue peak, plain and weighted with the two issue classes the
     micro-benchmark finds (share of the slow class from the static instruction mix of the sweep loops)."""
@@ -791,6 +797,16 @@ def valu_roofline(rec, n, k_ms):
         out["class_weighted_frac"] = (v / 1024.0) * ns * 1e-9 / t      # 1024 SIMDs
         out["class_weighted_how"] = "per SIMD: instructions x (%.2f ns fast class, %.2f ns slow class; tools/ubench/valu_rate.hip) / kernel time" % (
             VALU_NS_FAST, VALU_NS_SLOW)
+    alg = ALGORITHMIC_TABLE_LOGSUMS_PER_READ.get(workload)
+    if alg:
+        # the reference's own work at this kernel's rate, against the same issue peak in lane operations (x 64 lanes): what the
+        # executed count above leaves out is the work the position pruning / restarted sweeps do not do
+        lane_ops = alg * LANE_OPS_PER_LOGSUM * n / t
+        out["algorithmic"] = {"table_logsums_per_read": alg, "lane_ops_per_logsum": LANE_OPS_PER_LOGSUM,
+                              "lane_ops_per_s": lane_ops, "frac_of_issue_peak": lane_ops / (VALU_ISSUE_PEAK * 64.0),
+                              "executed_over_algorithmic": (v / n * 64.0) / (alg * LANE_OPS_PER_LOGSUM),
+                              "how": "SURVEY.md 8(d): the reference's logsum evaluations that reach the table, per read, x 10 lane operations, "
+                                     "x this kernel's reads/s, / (issue peak x 64 lanes)"}
     return out
 
 
