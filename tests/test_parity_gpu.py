@@ -72,6 +72,36 @@ def test_hip_vs_reference_fixture(ctx, name):
     assert np.array_equal(cnt[8:], bins)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c3_b6_s_r_p", "c2_b4_r", "c5_b96_f_r_p"])
+def test_tiles_of_tiny_reads(ctx, name):
+    """Tiles whose longest read is a handful of bases: S + 1 .. S + 12, 64 reads of each length, so that every tile's position
+    loops end inside their first block (the request rings of the light sweep groups, the label DP and the traceback run in
+    blocks of 2-4 positions and finish with a partial one).  HIP == oracle."""
+    from oracle import pyoracle
+    g = load_golden(name)
+    S = int(g["S"])
+    lens = np.repeat(np.arange(S + 1, S + 13), 64)
+    rng = np.random.RandomState(77)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    seq = rng.randint(0, 4, int(offs[-1])).astype(np.uint8)
+    seq[rng.random_sample(len(seq)) < 0.02] = 4
+    src_off = g["offs"]
+    for i in range(0, len(lens), 2):   # prefixes of real reads, so that barcodes are found
+        k = i % int(g["n_reads"])
+        s_ = g["seq"][src_off[k]:src_off[k + 1]][:lens[i]]
+        seq[offs[i]:offs[i] + len(s_)] = s_
+    ores, olab, oseq = pyoracle.label_batch(pyoracle.OracleModel(g), seq, offs, float(g["threshold"]), int(g["minlen"]), int(g["dust"]), 4)
+    res, labels, seq_after = _run(ctx, g, seq, offs)
+    for k in ("b_score", "f_score", "r_score", "bar_prob"):
+        assert np.array_equal(_bits(res[k]), _bits(ores[k])), k
+    assert np.array_equal(labels, olab)
+    assert np.allclose(res["mapq"], ores["Q"], rtol=0, atol=Q_TOL)
+    for k in ("read_type", "barcode", "fingerprint"):
+        assert np.array_equal(res[k], ores[k]), k
+    assert np.array_equal(seq_after, oseq)
+
+
 @pytest.mark.parametrize("name", ["c2_b4_r", "c3_b6_s_r_p", "scen2_endloss", "umi_f_s_r"])
 def test_hip_vs_oracle_fresh_reads(ctx, name):
     """Fresh seeded reads (uniform random with occasional N, ragged lengths incl. 1-base reads) through
