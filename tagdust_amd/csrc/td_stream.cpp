@@ -20,6 +20,9 @@
 #include <unistd.h>
 
 #include <math.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <chrono>
 #include <cmath>
@@ -359,9 +362,51 @@ inline int put_q(char* w, float q)
 // formats the records of one piece sub-range into one buffer per output file (print_all(), io.c:917-1001)
 struct OutBufs { std::vector<Bytes> file; };
 
+// The rewritten sequence of a read is base codes 0..4 with removed positions as 65: the stretches of kept bases become the
+// records.  Sixteen bytes at a time where the host has SSE2 (every x86-64 has): the write stage is the slower host stage of the
+// pipeline, and these two loops were half of its formatting time.
+#if defined(__SSE2__)
+// number of leading bytes of s[0, n) that are >= 5 (GE = true) / < 5 (GE = false)
+template <bool GE>
+inline int64_t span_of(const uint8_t* s, int64_t n)
+{
+	int64_t g = 0;
+	const __m128i five = _mm_set1_epi8(5);
+	for (; g + 16 <= n; g += 16) {
+		const __m128i v = _mm_loadu_si128((const __m128i*)(s + g));
+		const unsigned ge = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_max_epu8(v, five), v));   // bit k: s[g + k] >= 5
+		const unsigned stop = GE ? (~ge & 0xFFFFu) : ge;   // first byte that ends the span
+		if (stop) return g + __builtin_ctz(stop);
+	}
+	while (g < n && ((s[g] >= 5) == GE)) g++;
+	return g;
+}
+// w[k] = "ACGTN"[s[k]] for codes 0..4
+inline void codes_to_text(char* w, const uint8_t* s, size_t n)
+{
+	size_t k = 0;
+	const __m128i a = _mm_set1_epi8('A'), c1 = _mm_set1_epi8(1), c2 = _mm_set1_epi8(2), c3 = _mm_set1_epi8(3), c4 = _mm_set1_epi8(4);
+	const __m128i d1 = _mm_set1_epi8('C' - 'A'), d2 = _mm_set1_epi8('G' - 'A'), d3 = _mm_set1_epi8('T' - 'A'), d4 = _mm_set1_epi8('N' - 'A');
+	for (; k + 16 <= n; k += 16) {
+		const __m128i v = _mm_loadu_si128((const __m128i*)(s + k));
+		__m128i o = a;
+		o = _mm_add_epi8(o, _mm_and_si128(_mm_cmpeq_epi8(v, c1), d1));
+		o = _mm_add_epi8(o, _mm_and_si128(_mm_cmpeq_epi8(v, c2), d2));
+		o = _mm_add_epi8(o, _mm_and_si128(_mm_cmpeq_epi8(v, c3), d3));
+		o = _mm_add_epi8(o, _mm_and_si128(_mm_cmpeq_epi8(v, c4), d4));
+		_mm_storeu_si128((__m128i*)(w + k), o);
+	}
+	static const char alphabet[] = "ACGTNN";
+	for (; k < n; k++) w[k] = alphabet[s[k]];
+}
+#else
+template <bool GE>
+inline int64_t span_of(const uint8_t* s, int64_t n) { int64_t g = 0; while (g < n && ((s[g] >= 5) == GE)) g++; return g; }
+inline void codes_to_text(char* w, const uint8_t* s, size_t n) { static const char alphabet[] = "ACGTNN"; for (size_t k = 0; k < n; k++) w[k] = alphabet[s[k]]; }
+#endif
+
 void format_records(const Batch& b, const Piece& pc, int64_t lo, int64_t hi, int num_alternatives, OutBufs& out)
 {
-	static const char alphabet[] = "ACGTNN";
 	const char* text = pc.blk->data;
 	const std::vector<TdRec>& recs = *pc.recs;
 	char head[96];
@@ -379,9 +424,9 @@ void format_records(const Batch& b, const Piece& pc, int64_t lo, int64_t hi, int
 		int head_len = -1;
 		int64_t g = 0;
 		while (g < len) {
-			while (g < len && s[g] >= 5) g++;                  // removed positions (65) split the read into records
+			g += span_of<true>(s + g, len - g);                // removed positions (65) split the read into records
 			const int64_t g0 = g;
-			while (g < len && s[g] < 5) g++;
+			g += span_of<false>(s + g, len - g);
 			if (g == g0) break;
 			if (f < n_files) {                                 // io.c:955-975: "@<name>[;FP:%d];RQ:%0.2f"
 				if (head_len < 0) {
@@ -399,7 +444,7 @@ void format_records(const Batch& b, const Piece& pc, int64_t lo, int64_t hi, int
 				*w++ = '@';
 				memcpy(w, text + rec.name_off, (size_t)rec.name_len); w += rec.name_len;
 				memcpy(w, head, (size_t)head_len); w += head_len;
-				for (size_t k = 0; k < run; k++) w[k] = alphabet[s[g0 + (int64_t)k]];
+				codes_to_text(w, s + g0, run);
 				w += run;
 				*w++ = '\n'; *w++ = '+'; *w++ = '\n';
 				if (q) memcpy(w, q + g0, run); else memset(w, '.', run);
