@@ -1064,6 +1064,8 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 	if (!s.staged) return fail(c, "td_run: no batch resident (td_batch_upload failed or was not called)");
 	HIPCHK(c, hipSetDevice(c->device));
 	s.mode = mode; s.finished = false;
+	s.runs_cap = 0;   // (set again below when the specialised kernel leaves label runs: a batch through the generic kernel, or an
+	                  // empty one, must not hand the runs of this slot's previous batch to the finish kernel)
 	if (s.n_tiles == 0) { s.ran = true; s.last_ms = 0.0f; return TD_OK; }
 	if (c->spec_ready && c->match_len > 0 && !c->spec_window) {   // first batch through a window: the kernel variant that applies it
 		HIPCHK(c, sync_compute(c));
@@ -1113,7 +1115,6 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 		sa.ws = ka.ws; sa.lay = s.slay;
 		sa.lmax = s.n_big > 0 ? s.lmax_small : s.lmax;
 		sa.n_big = s.n_big; sa.lmax_big = s.lmax; sa.lay_big = s.slay_big; sa.out_lmax = s.lmax;
-		s.runs_cap = 0;
 		if (mode == TD_MODE_GET_LABEL) {   // the label runs for the compact egress, and the flag that says a read had more of them
 			const int cap = rle_capacity(c);
 			const size_t words = (size_t)s.n_tiles * (size_t)cap * TD_WAVE + 1;

@@ -400,3 +400,38 @@ def test_compact_egress_equals_plain_copies(name, monkeypatch):
     assert np.array_equal(outs["compact"][1], g["labels"]) and np.array_equal(outs["compact"][2], g["seq_after"])
     for k in ("plain", "overflow", "text", "pinned"):
         assert outs[k][0] == outs["compact"][0] and np.array_equal(outs[k][1], outs["compact"][1]) and np.array_equal(outs[k][2], outs["compact"][2]), k
+
+
+@pytest.mark.gpu
+def test_generic_kernel_after_specialised_kernel_in_one_context():
+    """One context, one slot: a batch through the model-specialised kernel (which leaves the label runs of the compact egress
+    itself), then -- "specialize" switched off, model uploaded again -- a batch of three times as many reads through the generic
+    kernel, whose labels the finish kernel has to scan.  The second batch must not be handed the first one's runs (their table
+    is sized for the first batch), through the synchronous calls and through the pipelined ones."""
+    from tagdust_amd import RESULT_DTYPE
+    g = load_golden("c2_b4_r")
+    n = int(g["n_reads"])
+    offs1 = np.ascontiguousarray(g["offs"], np.int64)
+    seq1 = np.ascontiguousarray(g["seq"], np.uint8)
+    reps = 3
+    seq3 = np.tile(seq1, reps)
+    offs3 = np.concatenate([[0], np.cumsum(np.tile(np.diff(offs1), reps))]).astype(np.int64)
+    lab3 = np.tile(g["labels"], reps)
+    c = _ctx(g, 1, depth=1)
+    try:
+        for pipelined in (False, True):
+            c.set_option("specialize", 1); c.upload_model(g); c.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+            res = np.zeros(n, RESULT_DTYPE); lab = np.full(int(offs1[-1]) + n, 99, np.int8); sq = np.full(int(offs1[-1]), 99, np.uint8)
+            c.wait(c.submit(seq1, offs1, res=res, labels=lab, seq_out=sq))
+            assert np.array_equal(lab, g["labels"])
+            c.set_option("specialize", 0); c.upload_model(g); c.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+            if pipelined:
+                res = np.zeros(n * reps, RESULT_DTYPE); lab = np.full(int(offs3[-1]) + n * reps, 99, np.int8); sq = np.full(int(offs3[-1]), 99, np.uint8)
+                c.wait(c.submit(seq3, offs3, res=res, labels=lab, seq_out=sq))
+            else:
+                c.upload_batch(seq3, offs3)
+                c.run()
+                res, lab, sq = c.download()
+            assert np.array_equal(lab, lab3) and np.array_equal(sq, np.tile(g["seq_after"], reps))
+    finally:
+        c.close()

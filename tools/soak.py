@@ -76,14 +76,20 @@ def main():
     hip = ctypes.CDLL("libamdhip64.so")
     free0, tot = ctypes.c_size_t(), ctypes.c_size_t()
     errors = []
-    worker("warm", 10, 0, errors)
+
+    def two_threads(n, seed):
+        th = [threading.Thread(target=worker, args=("t%d" % t, n, seed + t, errors)) for t in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    # warm-up with the same two threads: the runtime keeps what it allocates per hardware queue (the kernels' scratch backing,
+    # ~1 GB per queue that has run the decode kernel) -- that is not growth
+    two_threads(12, 0)
     hip.hipMemGetInfo(ctypes.byref(free0), ctypes.byref(tot))
     r0 = rss_mb()
-    th = [threading.Thread(target=worker, args=("t%d" % t, iters, 100 + t, errors)) for t in range(2)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
+    two_threads(iters, 100)
     free1 = ctypes.c_size_t()
     hip.hipMemGetInfo(ctypes.byref(free1), ctypes.byref(tot))
     print("iterations per thread:", iters, "errors:", errors)
