@@ -23,7 +23,7 @@ def rss_mb():
 
 def worker(tag, iters, seed, errors):
     rng = np.random.default_rng(seed)
-    fixtures = [load_golden(n) for n in ("c2_b4_r", "c3_b6_s_r_p", "umi_f_s_r", "scen2_endloss")]
+    fixtures = [load_golden(n) for n in ("c2_b4_r", "c3_b6_s_r_p", "umi_f_s_r", "scen2_endloss", "c5_b96_f_r_p")]
     c = TagdustHip(0)
     ref = {}
     try:
@@ -36,7 +36,7 @@ def worker(tag, iters, seed, errors):
                 c.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
                 ref["cur"] = k
             n_all = int(g["n_reads"])
-            n = int(rng.choice([0, 1, 63, 64, 65, n_all // 2, n_all]))
+            n = min(n_all, int(rng.choice([0, 1, 63, 64, 65, n_all // 2, n_all])))
             pick = np.sort(rng.choice(n_all, n, replace=False)) if n else np.zeros(0, np.int64)
             reps = int(rng.choice([1, 1, 40, 400])) if n else 1          # sometimes a large batch of repeated reads
             offs_g = g["offs"]
@@ -58,6 +58,14 @@ def worker(tag, iters, seed, errors):
                     errors.append("%s: iteration %d: two submissions of one batch differ" % (tag, it))
                     return
                 res, labels, seq_after = outs[1]
+            if n:   # labels and rewritten sequences of the first and the last repetition, byte for byte
+                lab_g = np.concatenate([g["labels"][offs_g[i] + i:offs_g[i + 1] + i + 1] for i in pick])
+                seq_g = np.concatenate([g["seq_after"][offs_g[i]:offs_g[i + 1]] for i in pick])
+                nb = int(offs[n])
+                for r in (0, reps - 1):
+                    if not (np.array_equal(labels[r * (nb + n):(r + 1) * (nb + n)], lab_g) and np.array_equal(seq_after[r * nb:(r + 1) * nb], seq_g)):
+                        errors.append("%s: iteration %d fixture %d n %d reps %d: labels / sequences differ" % (tag, it, k, n, reps))
+                        return
             for r in range(0, reps, max(1, reps // 2)):
                 sl = slice(r * n, (r + 1) * n)
                 if not (np.array_equal(res["read_type"][sl], g["read_type"][pick]) and np.array_equal(res["barcode"][sl], g["barcode"][pick])
