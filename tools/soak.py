@@ -43,6 +43,17 @@ def worker(tag, iters, seed, errors):
             seqs = [g["seq"][offs_g[i]:offs_g[i + 1]] for i in pick] * reps
             offs = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int64)
             seq = np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)
+            if it % 7 == 3 and n:                   # now and then a probability-only pass over the batch first (MODE_GET_PROB: no
+                from tagdust_amd.lib import MODE_GET_PROB   # labels, no runs), or a pipelined batch that asks for the records alone
+                if it % 2:
+                    c.upload_batch(seq, offs); c.run(MODE_GET_PROB); c.download(labels=False, seq=False)
+                else:
+                    from tagdust_amd import RESULT_DTYPE
+                    r_only = np.zeros(len(offs) - 1, RESULT_DTYPE)
+                    c.wait(c.submit(seq, offs, res=r_only))
+                    if not np.array_equal(r_only["read_type"][:n], g["read_type"][pick]):
+                        errors.append("%s: iteration %d: records-only submission differs" % (tag, it))
+                        return
             if it % 2 == 0:                         # the synchronous calls ...
                 c.upload_batch(seq, offs)
                 c.run()
