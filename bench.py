@@ -837,12 +837,45 @@ def load_traffic(n, workload):
     return (rec.get("hbm_bytes_per_launch") if rec else None), note
 
 
+def _code_only(text):
+    """C / C++ source without its comments and with runs of white space collapsed (string and character literals kept as they
+    are): what the compiler sees, give or take line numbers."""
+    out = []
+    i, n = 0, len(text)
+    while i < n:
+        ch = text[i]
+        if ch == '"' or ch == "'":
+            j = i + 1
+            while j < n and text[j] != ch:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1]); i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        elif ch in " \t\r\n":
+            j = i
+            while j < n and text[j] in " \t\r\n":
+                j += 1
+            out.append("\n" if "\n" in text[i:j] else " "); i = j
+        else:
+            out.append(ch); i += 1
+    import re
+    t = "".join(out)
+    t = re.sub(r"[ \t]*\n[ \t\n]*", "\n", t)     # (a comment line leaves its line break behind: fold those too)
+    return re.sub(r"[ \t]+", " ", t).strip()
+
+
 def kernel_source_sha16():
-    """Hash of the files the decode kernel is built from: ties a PMC record to the code it measured."""
+    """Hash of the files the decode kernel is built from, comments and white space aside: ties a PMC record to the code it
+    measured (a comment may be corrected without re-measuring; any token that reaches the compiler may not)."""
     import hashlib
     h = hashlib.sha256()
     for fn in ("td_spec_kernel.inc", "td_artifact.inc", "td_device.h", "td_jit.hip", "td_kernels.hip"):
-        h.update(open(os.path.join(REPO, "tagdust_amd", "csrc", fn), "rb").read())
+        h.update(_code_only(open(os.path.join(REPO, "tagdust_amd", "csrc", fn), "r").read()).encode())
     return h.hexdigest()[:16]
 
 
