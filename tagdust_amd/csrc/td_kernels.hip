@@ -797,9 +797,23 @@ __device__ __forceinline__ void decode_body(const TdKernelArgs& ka, const int bl
 			ka.out_barcode[rid] = barcode;
 			ka.out_finger[rid] = fingerprint;
 		}
-		if (ka.mode == MODE_GET_LABEL && lenF >= 1) {
-			atomicAdd(&ka.counters[read_type & (N_OUTCOME_SLOTS - 1)], 1ull);
-			if (read_type == OUT_SUCCESS && barcode >= 0) atomicAdd(&ka.counters[N_OUTCOME_SLOTS + (barcode & 0xFF)], 1ull);
+		if (ka.mode == MODE_GET_LABEL) {
+			// one atomic per wave and distinct value (see td_spec_kernel.inc: a million atomics on two or three words hold up
+			// every memory operation of the machine)
+			const int key1 = (lenF >= 1) ? (read_type & (N_OUTCOME_SLOTS - 1)) : -1;
+			const int key2 = (lenF >= 1 && read_type == OUT_SUCCESS && barcode >= 0) ? N_OUTCOME_SLOTS + (barcode & 0xFF) : -1;
+#pragma unroll
+			for (int pass = 0; pass < 2; pass++) {
+				const int key = pass ? key2 : key1;
+				unsigned long long todo = __builtin_amdgcn_ballot_w64(key >= 0);
+				while (todo) {
+					const int leader = __builtin_ctzll(todo);
+					const int kv = __builtin_amdgcn_readlane(key, leader);
+					const unsigned long long same = __builtin_amdgcn_ballot_w64(key == kv);
+					if (lane == leader) atomicAdd(&ka.counters[kv], (unsigned long long)__builtin_popcountll(same));
+					todo &= ~same;
+				}
+			}
 		}
 	}
 }
