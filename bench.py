@@ -558,8 +558,10 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     host = bind_rank_to_numa(dev_index, local_rank, local_world)
-    # host threads of the library's copy pool (pageable caller memory <-> pinned staging): the rank's share of the CPUs, at most 8
-    os.environ.setdefault("TD_HOST_THREADS", str(max(2, min(8, host["cpus"] // 2))))
+    # host threads of the library's copy pool (pageable caller memory <-> pinned staging, rebuilding sequences and labels from the
+    # compact egress): the rank's share of the CPUs, at most 16 (the decode launch takes 15 ms per 2^20 reads now: the host's
+    # 12 ms per step on 8 threads no longer hide behind it with room to spare)
+    os.environ.setdefault("TD_HOST_THREADS", str(max(2, min(16, host["cpus"] // 2))))
     dist = None
     use_dist = world > 1 or os.environ.get("TD_BENCH_FORCE_DIST") == "1"   # the latter: a 1-rank RCCL group on a one-GPU box
     if use_dist:
