@@ -37,6 +37,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0  # ... of which streaming kernels reach about 6.3 TB/s (same guide)
 READ_LEN = 150
 BARCODES = ["TTGTGT", "AAAAAA", "AAACCC", "AAAGGG", "AAATTT", "AACACG", "AACCAT", "AACGTA"]  # first 8 of EDITTAG_6nt_ed_3
 SPACER = "GTA"
@@ -700,6 +701,11 @@ def main():
                          "algorithmic_bytes_per_read": bpr, "reads_per_launch": n,
                          "traffic_gbps": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
                          "traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "traffic_frac_of_achievable": (traffic / (k_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS) if traffic else None,
+                         "lds": ({"idx_active_share": rec.get("lds_idx_active_share_of_cu_cycles"),
+                                  "bank_conflict_share": rec.get("lds_bank_conflict_share"),
+                                  "how": "SQ_LDS_IDX_ACTIVE / CU cycles of the launch, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (PMC passes of the "
+                                         "same kernel source, profiles/): the logsum table gather"} if rec else None),
                          "traffic_source": traffic_note,
                          "valu": valu_roofline(rec, n, k_ms, args.workload),
                          "note": "algorithmic bytes are tiny (SURVEY.md 8d: not HBM-bound); the kernel's real HBM traffic is the "

@@ -67,7 +67,12 @@ int  td_writer_close(td_writer* w);
  * writer thread formats and appends finished batches (n_threads threads; every output file keeps input order).  A plain
  * file is mapped, not read.  Batches hold exactly batch_reads records, whatever the block size.
  * The output files are those td_writer_open names, byte for byte what td_reads_parse / td_writer_write give for the whole
- * text at once.  ctx == NULL: a parse-only run (no GPU, nothing written) that fills stats, codes_fnv included. */
+ * text at once.  ctx == NULL: a parse-only run (no GPU, nothing written) that fills stats, codes_fnv included.
+ * Errors: a decompressor that ends with a non-zero status (truncated / corrupt .gz, .bz2) fails the run -- the reference
+ * ignores pclose()'s status and writes a partial file set.  A mapped plain file must not shrink while the call runs (the parse
+ * threads read the mapping; the kernel answers a truncated mapping with SIGBUS, as for any mmap reader).  When page-locked
+ * memory runs short the pipeline runs with the batches it could get (at least one), more slowly, and fails with "page-locked
+ * memory exhausted" only if not even a single batch fits. */
 typedef struct td_stream_opts {
 	int32_t batch_reads;   /* records per batch; 0 = 1 000 001 (param->num_query, src/barcode_hmm.c:172) when the context has a
 	                          -ref artifact filter -- its per-thread read ranges are taken over a batch, so the boundaries are part

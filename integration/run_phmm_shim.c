@@ -16,7 +16,8 @@
  * mode TAGDUST_HIP_DELEGATE=<mode>[,<mode>] names (a debugging aid: e.g. "4" runs the threshold calibration on the CPU and
  * the labelling on the GPU inside one binary).  Every hand-over is counted, and at exit the shim reports
  *     tagdust_hip: batches gpu=<n> delegated=<m>
- * on stderr.  TAGDUST_HIP_STRICT=1 turns a hand-over into an error (run_pHMM returns kslFAIL with a message), so that a
+ * on stderr when TAGDUST_HIP_REPORT=1 or TAGDUST_HIP_STRICT=1 is set, or when a batch was handed over (otherwise the binary's
+ * stderr is the reference's own).  TAGDUST_HIP_STRICT=1 turns a hand-over into an error (run_pHMM returns kslFAIL with a message), so that a
  * test -- or a user -- can be sure that every result came from the GPU.
  *
  * Inputs on which the reference itself has no defined behaviour are not handed to it: a -start/-end window with
@@ -48,9 +49,14 @@ static uint64_t g_model_key = 0;
 static long g_batches_gpu = 0, g_batches_delegated = 0;
 static int g_report_registered = 0;
 
+/* The drop-in binary's stderr stays the reference's own unless somebody asked (TAGDUST_HIP_REPORT=1, TAGDUST_HIP_STRICT=1) or a
+ * batch was in fact handed to the CPU path -- which a user should hear about. */
 static void report_at_exit(void)
 {
-	fprintf(stderr, "tagdust_hip: batches gpu=%ld delegated=%ld\n", g_batches_gpu, g_batches_delegated);
+	const char* rep = getenv("TAGDUST_HIP_REPORT");
+	const char* strict = getenv("TAGDUST_HIP_STRICT");
+	if ((rep && atoi(rep) != 0) || (strict && atoi(strict) != 0) || g_batches_delegated > 0)
+		fprintf(stderr, "tagdust_hip: batches gpu=%ld delegated=%ld\n", g_batches_gpu, g_batches_delegated);
 }
 
 static void ensure_report(void)
@@ -251,8 +257,9 @@ int run_pHMM(struct arch_bag* ab, struct model_bag* mb, struct read_info** ri, s
 	int i, k, status = kslOK;
 
 	const int windowed = param->matchstart != -1 || param->matchend != -1;
-	/* not on the GPU path: the dead training modes; -start/-end windows when a read does not reach matchend -- the
-	   reference reads past the end of such a read (undefined), so its own code keeps that case */
+	/* not on the GPU path: the dead training modes only.  (-start/-end windows run on the device in every mode; a read that does
+	   not reach matchend -- which the reference decodes past its terminator, corrupting its heap -- is decoded on the bases it
+	   has inside the window, and an invalid window is refused below: neither is handed to the reference's code.) */
 	if (mode != MODE_GET_LABEL && mode != MODE_GET_PROB && mode != MODE_ARCH_COMP)
 		return delegate("a training mode (dead code in v2.33)", ab, mb, ri, param, reference_fasta, numseq, mode);
 	if (mode == MODE_ARCH_COMP && !ab) return delegate("architecture comparison without candidates", ab, mb, ri, param, reference_fasta, numseq, mode);

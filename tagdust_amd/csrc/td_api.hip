@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include <condition_variable>
 #include <deque>
@@ -49,21 +50,28 @@ static float p2sp(float p) { return p == 0.0f ? -INFINITY : (float)log((double)p
 // the device counter block: what the ABI reports, then the diagnostic tail of the development knobs (td_diag_get)
 #define TD_COUNTER_WORDS (TD_NUM_COUNTERS + TD_NUM_DIAG_COUNTERS)
 
-// One batch on its way through the device (see "batches" below).
-struct TdSlot {
+// One batch on its way through the device (see "batches" below).  What a slot knows about ITS BATCH lives in three groups, each
+// value-initialised as a whole by the step that owns it -- so that nothing a branch of that step does not set can survive from
+// the batch before (round 3's soak fault was exactly that: a label-run table of the previous, smaller batch):
+//   TdStaged  <- slot_stage():       the reads as staged on the device and the workspace geometry chosen for them
+//   TdDecoded <- slot_decode():      what the last launch over the staged batch was and left behind
+//   TdFetch   <- slot_fetch_begin(): where the results go and in which form they travel
+// slot_stage() also resets the two later groups, slot_decode() the last one.  What is left in TdSlot itself belongs to the slot,
+// not to a batch: device / pinned buffers with their capacities, events, the ticket.
+struct TdRoute {             // where a batch runs (chosen by the caller of slot_stage, per batch)
+	hipStream_t cs = nullptr;   // the compute stream (c->stream, or c->stream2 for every other pipelined batch)
+	hipStream_t aux = nullptr;  // the stream of its sort / pack kernels: cs itself, or the context's high-priority stream for them
+	hipStream_t fin = nullptr;  // ... and of its finish kernel (a stream of its own: it waits for the decode kernel, the next batch's pack must not)
+	int wsi = 0;                // ... and the workspace (0 / 1) that goes with cs
+	bool pipelined = false;     // a td_submit batch (the synchronous calls use slot 0 with pipelined = false)
+};
+struct TdStaged : TdRoute {
 	int64_t n_reads = 0, n_bases = 0;
 	int32_t n_tiles = 0, lmax = 0, nw2 = 0, nw1 = 0;
-	int is_ascii = 0, mode = 0;
+	int is_ascii = 0;
 	bool sorted = false;      // device order differs from the caller's (reads of several lengths)
 	bool staged = false;      // inputs are packed on the device: td_run may launch
-	bool ran = false, finished = false;
-	float last_ms = -1.0f;
-	int64_t ticket = 0;       // td_submit: 0 = free
-	td_read_result* u_res = nullptr; int8_t* u_labels = nullptr; uint8_t* u_seq = nullptr;   // the caller's output buffers
-	bool res_direct = false, lab_direct = false, seq_direct = false;                          // ... are page-locked
-	bool copies_deferred = false;   // td_wait issues the device-to-host copies (pipelined calls)
-	bool raw_direct = false;        // the upload reads the caller's page-locked buffer itself (no staging copy)
-	bool pipelined = false;         // a td_submit batch (the synchronous calls use slot 0 with pipelined = false)
+	bool raw_direct = false;  // the upload read the caller's page-locked buffer itself (no staging copy)
 	TdStageBatch sb{};
 	TdWsLayout lay{};
 	TdSpecLayout slay{};
@@ -74,10 +82,26 @@ struct TdSlot {
 	int32_t n_long = 0, lmax_small = 0, n_big = 0;
 	TdSpecLayout slay_big{};
 	int64_t ws_bytes = 0;       // workspace bytes this batch's launch uses
-	hipStream_t cs = nullptr;   // the compute stream this batch runs on (c->stream, or c->stream2 for every other pipelined batch)
-	hipStream_t aux = nullptr;  // the stream of its sort / pack kernels: cs itself, or the context's high-priority stream for them
-	hipStream_t fin = nullptr;  // ... and of its finish kernel (a stream of its own: it waits for the decode kernel, the next batch's pack must not)
-	int wsi = 0;                // ... and the workspace (0 / 1) that goes with it
+};
+struct TdDecoded {
+	int mode = 0;
+	bool ran = false;
+	float last_ms = -1.0f;
+	int32_t runs_cap = 0;       // entries per read in d_runs (0: the last launch left no label runs)
+};
+struct TdFetch {
+	td_read_result* u_res = nullptr; int8_t* u_labels = nullptr; uint8_t* u_seq = nullptr;   // the caller's output buffers
+	bool res_direct = false, lab_direct = false, seq_direct = false;                          // ... are page-locked
+	bool copies_deferred = false;   // td_wait issues the device-to-host copies (pipelined calls)
+	bool use_keep = false, use_rle = false;   // compact egress: keep bits instead of the rewritten sequence, label runs instead of labels
+	int32_t rle_cap = 0;
+	bool finished = false;          // the finish kernel is queued: slot_fetch_end has something to collect
+};
+struct TdSlot : TdStaged, TdDecoded, TdFetch {
+	int64_t ticket = 0;       // td_submit: 0 = free
+	void reset_staged(const TdRoute& r) { static_cast<TdStaged&>(*this) = TdStaged(); static_cast<TdRoute&>(*this) = r; reset_decoded(); }
+	void reset_decoded() { static_cast<TdDecoded&>(*this) = TdDecoded(); reset_fetch(); }
+	void reset_fetch() { static_cast<TdFetch&>(*this) = TdFetch(); }
 	// device
 	uint8_t* d_raw = nullptr;      size_t cap_raw = 0;
 	int64_t* d_offs = nullptr;     size_t cap_offs = 0;
@@ -96,11 +120,8 @@ struct TdSlot {
 	uint32_t* d_keepo = nullptr;   size_t cap_keepo = 0;
 	uint32_t* d_rle = nullptr;     size_t cap_rle = 0;     // (+ one word behind the runs: the overflow flag)
 	uint32_t* d_runs = nullptr;    size_t cap_runs = 0;    // label runs in device order, left by the specialised kernel (+ the overflow flag)
-	int32_t runs_cap = 0;          // entries per read in d_runs (0: the last launch left none)
 	uint32_t* h_keepo = nullptr;   size_t cap_h_keepo = 0;
 	uint32_t* h_rle = nullptr;     size_t cap_h_rle = 0;
-	bool use_keep = false, use_rle = false;
-	int32_t rle_cap = 0;
 	// pinned host staging for pageable caller memory
 	uint8_t* h_raw = nullptr;      size_t cap_h_raw = 0;
 	int64_t* h_offs = nullptr;     size_t cap_h_offs = 0;
@@ -127,7 +148,30 @@ static int default_host_threads()
 // six then share one, and whatever sits behind a 20 ms decode launch in its queue waits for it.  Eight leaves every stream its
 // own queue (measured on one box: 17.6 / 17.6 ms per 2^20-read step against 17.6 / 18.5 with four).  The runtime reads the
 // variable when it initialises, at the process's first HIP call; a value the user has set is left alone.
-__attribute__((constructor)) static void td_want_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// That works when this library is loaded before the process's first HIP call (the drop-in binary, the Python harness); a host
+// that initialised HIP first keeps the runtime's own default, and can see so: td_get_option("hw_queues") is what the runtime
+// was configured with when it initialised as far as this library can tell, "hw_queues_late" says the request came too late.
+// (Whether the runtime is up is read off the process's open files: initialising it opens /dev/kfd.)
+static int g_hwq_user = 0;       // GPU_MAX_HW_QUEUES as the user had set it when the library was loaded (0: not set)
+static bool g_hwq_late = false;  // ... the HIP runtime was already initialised then
+static bool kfd_is_open()
+{
+	char path[64], target[64];
+	for (int fd = 0; fd < 256; fd++) {
+		snprintf(path, sizeof path, "/proc/self/fd/%d", fd);
+		const ssize_t n = readlink(path, target, sizeof target - 1);
+		if (n <= 0) continue;
+		target[n] = 0;
+		if (!strcmp(target, "/dev/kfd")) return true;
+	}
+	return false;
+}
+__attribute__((constructor)) static void td_want_hw_queues()
+{
+	if (const char* e = getenv("GPU_MAX_HW_QUEUES")) { g_hwq_user = atoi(e) > 0 ? atoi(e) : 0; if (g_hwq_user) return; }
+	g_hwq_late = kfd_is_open();
+	if (!g_hwq_late) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
 
 struct CopyPool {
 	struct Job { char* dst; const char* src; size_t bytes; const std::function<void(int64_t, int64_t)>* fn; int64_t lo, hi; };
@@ -255,7 +299,19 @@ struct td_ctx {
 	// batches: slot 0 is the resident batch of the synchronous calls; td_submit rotates over pipeline_depth slots
 	TdSlot slots[TD_MAX_PIPELINE];
 	int pipeline_depth = 3, next_slot = 0, last_slot = 0;
+	bool counted = false;   // td_ctx_create finished: this context counts among the live ones (the last one to go frees the stream cache)
 	int poison = 0;   // option "poison_workspace": fill the workspace with 0xFF bytes before every decode launch (tests)
+	// development / test knobs: read from the environment ONCE, when the context is created (never on the per-batch path), and
+	// settable afterwards through td_set_option under the names in brackets
+	int compact_egress = 1;    // TD_COMPACT_EGRESS ["compact_egress"]: keep bits + label runs instead of plain copies
+	int rle_cap_forced = 0;    // TD_RLE_CAP ["rle_cap"]: entries of the label-run table (0: S + 2)
+	int length_classes = 1;    // TD_NO_LENGTH_CLASSES ["length_classes_enabled"]
+	int debug_wait = 0;        // TD_DEBUG_WAIT ["debug_wait"]
+	int debug_alloc = 0;       // TD_DEBUG_ALLOC
+	long wave_slots_forced = 0;   // TD_WAVE_SLOTS
+	int ws_candidates = 3;     // TD_WS_CANDIDATES
+	double lsum_limit = 1.0e6; // TD_SPEC_LSUM_LIMIT (tests: force the switch to the clamped logsum)
+	int selfcheck_fail = 0;    // TD_SPEC_SELFCHECK_FAIL (tests: exercise the fallback)
 	int64_t ticket_counter = 0;
 	hipStream_t s_up = nullptr, s_down = nullptr;   // copy streams of the pipelined calls
 	uint8_t* d_ws = nullptr;      size_t cap_ws = 0;  // workspace of the decode kernels on `stream` (they run one after the other)
@@ -313,7 +369,7 @@ static int ensure(td_ctx* c, T** p, size_t* cap, size_t bytes)
 	if (bytes == 0) bytes = 256;
 	HIPCHK(c, hipMalloc((void**)p, bytes));
 	*cap = bytes;
-	if (getenv("TD_DEBUG_ALLOC") && bytes > (1u << 30)) fprintf(stderr, "tagdust_hip: hipMalloc(%zu) = %p\n", bytes, (void*)*p);
+	if (c && c->debug_alloc && bytes > (1u << 30)) fprintf(stderr, "tagdust_hip: hipMalloc(%zu) = %p\n", bytes, (void*)*p);
 	return TD_OK;
 }
 
@@ -340,6 +396,10 @@ extern "C" const char* td_last_error(const td_ctx* ctx)
 	return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
 
+extern "C" void td_stream_release(void);   // td_stream.cpp: the page-locked batch buffers td_stream_run keeps between runs
+static std::mutex g_live_mu;
+static int g_live_ctx = 0;
+
 extern "C" int td_ctx_create(int device, td_ctx** out)
 {
 	if (!out) return fail(nullptr, "td_ctx_create: out is NULL");
@@ -365,6 +425,15 @@ extern "C" int td_ctx_create(int device, td_ctx** out)
 	c->n_cu = prop.multiProcessorCount;
 	if (const char* e = getenv("TD_SPECIALIZE")) c->specialize = atoi(e) != 0;
 	if (const char* e = getenv("TD_OVERLAP")) c->overlap = atoi(e) != 0;
+	if (const char* e = getenv("TD_COMPACT_EGRESS")) c->compact_egress = atoi(e) != 0;
+	if (const char* e = getenv("TD_RLE_CAP")) { const int v = atoi(e); if (v >= 1 && v <= 127) c->rle_cap_forced = v; }
+	if (getenv("TD_NO_LENGTH_CLASSES")) c->length_classes = 0;
+	if (getenv("TD_DEBUG_WAIT")) c->debug_wait = 1;
+	if (getenv("TD_DEBUG_ALLOC")) c->debug_alloc = 1;
+	if (const char* e = getenv("TD_WAVE_SLOTS")) { const long v = atol(e); if (v > 0) c->wave_slots_forced = v; }
+	if (const char* e = getenv("TD_WS_CANDIDATES")) c->ws_candidates = atoi(e);
+	if (const char* e = getenv("TD_SPEC_LSUM_LIMIT")) c->lsum_limit = atof(e);
+	if (getenv("TD_SPEC_SELFCHECK_FAIL")) c->selfcheck_fail = 1;
 	c->hbm_total = prop.totalGlobalMem;
 	init_logsum_host();
 	bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -376,6 +445,7 @@ extern "C" int td_ctx_create(int device, td_ctx** out)
 		td_ctx_destroy(c);
 		return fail(nullptr, "td_ctx_create: HIP resource allocation failed: %s", hipGetErrorString(hipGetLastError()));
 	}
+	{ std::lock_guard<std::mutex> lk(g_live_mu); g_live_ctx++; c->counted = true; }
 	*out = c;
 	return TD_OK;
 }
@@ -405,7 +475,12 @@ extern "C" void td_ctx_destroy(td_ctx* c)
 	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	if (c->s_aux) (void)hipStreamDestroy(c->s_aux);
 	if (c->s_fin) (void)hipStreamDestroy(c->s_fin);
+	bool last = false;
+	if (c->counted) { std::lock_guard<std::mutex> lk(g_live_mu); last = --g_live_ctx == 0; }
 	delete c;
+	// td_stream_run keeps up to 1 GiB of page-locked batch buffers for the next run of the process: with the last context gone
+	// there is no next run to serve
+	if (last) td_stream_release();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -450,7 +525,7 @@ static int load_spec_kernel(td_ctx* c, int lsum_oob, int window = -1)
 		if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost);
 		(void)hipFree(d_pairs); (void)hipFree(d_bad);
 		if (e != hipSuccess) return fail(c, "td_model_upload: logsum self-check did not run: %s", hipGetErrorString(e));
-		if (getenv("TD_SPEC_SELFCHECK_FAIL") && lsum_oob) bad = 1;   // tests: exercise the fallback
+		if (c->selfcheck_fail && lsum_oob) bad = 1;   // tests: exercise the fallback
 		if (bad != 0) {
 			if (!lsum_oob) return fail(c, "td_model_upload: the compiled logsum differs from the reference formula on %d of %d operand pairs", bad, n_pairs);
 			fprintf(stderr, "tagdust_hip: clamp-free logsum failed its self-check on this device / toolchain (%d of %d pairs); using the clamped form\n", bad, n_pairs);
@@ -469,8 +544,7 @@ static int load_spec_kernel(td_ctx* c, int lsum_oob, int window = -1)
 // add two such values, so 4 * max|parameter| * (L + 2) bounds every finite difference; 6 * keeps a margin.
 static bool spec_lsum_range_ok(const td_ctx* c, int lmax)
 {
-	double limit = 1.0e6;
-	if (const char* e = getenv("TD_SPEC_LSUM_LIMIT")) limit = atof(e);   // tests: force the switch to the clamped form
+	const double limit = c->lsum_limit;   // (1e6; tests lower it to force the switch to the clamped form)
 	return 6.0 * (double)c->m_maxabs * ((double)lmax + 2.0) < limit;
 }
 
@@ -639,6 +713,15 @@ extern "C" int td_set_option(td_ctx* c, const char* name, int32_t value)
 		return TD_OK;
 	}
 	if (!strcmp(name, "poison_workspace")) { c->poison = value != 0; return TD_OK; }
+	if (!strcmp(name, "compact_egress")) { c->compact_egress = value != 0; return TD_OK; }          // takes effect with the next download / td_submit
+	if (!strcmp(name, "length_classes_enabled")) { c->length_classes = value != 0; return TD_OK; }  // ... the next upload
+	if (!strcmp(name, "debug_wait")) { c->debug_wait = value != 0; return TD_OK; }
+	if (!strcmp(name, "spec_lsum_limit")) { c->lsum_limit = value > 0 ? (double)value : 1.0e6; return TD_OK; }   // tests; next upload
+	if (!strcmp(name, "rle_cap")) {
+		if (value < 0 || value > 127) return fail(c, "td_set_option: rle_cap must be 0 (default) .. 127");
+		c->rle_cap_forced = value;
+		return TD_OK;
+	}
 	if (!strcmp(name, "host_threads")) {
 		if (value < 1 || value > 16) return fail(c, "td_set_option: host_threads must be 1..16");
 		c->host_threads = value;
@@ -668,6 +751,12 @@ extern "C" int td_get_option(td_ctx* c, const char* name, int32_t* value)
 	if (!strcmp(name, "artifacts_active")) { *value = c->art_n > 0; return TD_OK; }
 	if (!strcmp(name, "length_classes")) { *value = c->slots[c->last_slot].n_big; return TD_OK; }   // wave slots of the long geometry in the last batch
 	if (!strcmp(name, "overlap_decode")) { *value = c->overlap; return TD_OK; }
+	if (!strcmp(name, "compact_egress")) { *value = c->compact_egress; return TD_OK; }
+	if (!strcmp(name, "length_classes_enabled")) { *value = c->length_classes; return TD_OK; }
+	// hardware queues of the HIP runtime as far as the library can tell (see td_want_hw_queues): the user's GPU_MAX_HW_QUEUES, else
+	// the 8 the library asked for when it was loaded before the runtime initialised, else the runtime's own default of 4
+	if (!strcmp(name, "hw_queues")) { *value = g_hwq_user ? g_hwq_user : (g_hwq_late ? 4 : 8); return TD_OK; }
+	if (!strcmp(name, "hw_queues_late")) { *value = g_hwq_late ? 1 : 0; return TD_OK; }
 	// which fast paths the model / the last batch actually got (read-only)
 	if (!strcmp(name, "prune_active")) {
 		// the loaded specialised kernel prunes by position AND the bound tables of the last batch's geometry are live
@@ -847,7 +936,7 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 	// wave slots: enough to fill the chip (2 workgroups of 4 waves per CU share the LDS), bounded by HBM
 	const int wpb = (c->spec_ready ? c->spec_block : td_kernel_block_threads()) / TD_WAVE;
 	int64_t want = (int64_t)c->n_cu * (c->spec_ready ? c->spec_waves_per_cu : 2 * wpb);
-	if (const char* e = getenv("TD_WAVE_SLOTS")) { const long v = atol(e); if (v > 0) want = v; }
+	if (c->wave_slots_forced > 0) want = c->wave_slots_forced;
 	int64_t slots = want;
 	if (slots > s.n_tiles) slots = s.n_tiles;
 	if (slots < 1) slots = 1;
@@ -907,8 +996,7 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 			// Where the driver places a large allocation decides how fast the kernel's spill stream runs over it (up to
 			// 9 % on one box).  A large workspace is therefore chosen among a few candidates that
 			// exist side by side: a memory-side probe runs over each, the fastest stays, the others are freed.
-			int n_cand = 3;
-			if (const char* e = getenv("TD_WS_CANDIDATES")) n_cand = atoi(e);
+			int n_cand = c->ws_candidates;
 			if (n_cand > 4) n_cand = 4;
 			if (need < ((size_t)2 << 30) || (double)need * n_cand > 0.6 * (double)(free_b + cap_ws)) n_cand = 1;
 			if (n_cand <= 1) {
@@ -927,7 +1015,7 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 					if (best < 0 || ms[k] < ms[best]) best = k;
 				}
 				if (best < 0) return fail(c, "td_batch_upload: workspace of %zu bytes could not be allocated", need);
-				if (getenv("TD_DEBUG_ALLOC")) fprintf(stderr, "tagdust_hip: workspace candidates: probe %.2f %.2f %.2f %.2f ms -> #%d\n", ms[0], ms[1], ms[2], ms[3], best);
+				if (c->debug_alloc) fprintf(stderr, "tagdust_hip: workspace candidates: probe %.2f %.2f %.2f %.2f ms -> #%d\n", ms[0], ms[1], ms[2], ms[3], best);
 				for (int k = 0; k < n_ok; k++) if (k != best) (void)hipFree(cand[k]);
 				ws = cand[best]; cap_ws = need;
 			}
@@ -941,13 +1029,9 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 
 // Reads -> device, sorted and packed.  Copies go on `up` (the compute stream itself for the synchronous calls); the
 // kernels on the compute stream wait for them through ev_up.
-static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, const int64_t* offs, int64_t n, hipStream_t up, bool with_workspace = true)
+static int slot_stage(td_ctx* c, TdSlot& s, const TdRoute& route, const void* bases, int is_ascii, const int64_t* offs, int64_t n, hipStream_t up, bool with_workspace = true)
 {
-	s.staged = false; s.ran = false; s.finished = false;
-	s.n_reads = 0; s.n_tiles = 0;
-	if (!s.cs) { s.cs = c->stream; s.wsi = 0; }
-	if (!s.aux) s.aux = s.cs;
-	if (!s.fin) s.fin = s.cs;
+	s.reset_staged(route);   // nothing of the slot's previous batch survives (nor of its launch, nor of its download)
 	if (with_workspace && !c->have_model) return fail(c, "td_batch_upload: no model uploaded");
 	if (!offs || n < 0 || (!bases && n > 0 && offs[n] > offs[0])) return fail(c, "td_batch_upload: bad arguments");
 	if (n > 0x7fffffffLL - TD_WAVE) return fail(c, "td_batch_upload: %lld reads in one batch", (long long)n);
@@ -974,7 +1058,7 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 	// the reads at the 99 % mark, the tiles beyond that mark (n_long of them) get wave slots of their own geometry and the rest
 	// keeps the geometry of the many -- one 1000-base read among 150-base reads no longer costs every slot 6.6 times the memory.
 	s.n_long = 0; s.lmax_small = lmax;
-	if (c->spec_ready && with_workspace && lmin != lmax && n_tiles >= 64 && !getenv("TD_NO_LENGTH_CLASSES")) {
+	if (c->spec_ready && with_workspace && lmin != lmax && n_tiles >= 64 && c->length_classes) {
 		std::vector<int64_t> hist((size_t)lmax + 2, 0);
 		for (int64_t i = 0; i < n; i++) hist[(size_t)(offs[i + 1] - offs[i])]++;
 		// rank of the last read of the tile at the 99 % mark, its length, and the tiles that hold anything longer
@@ -1052,20 +1136,20 @@ static int slot_stage(td_ctx* c, TdSlot& s, const void* bases, int is_ascii, con
 static int rle_capacity(const td_ctx* c)
 {
 	int cap = c->hdr.S + 2 < c->hdr.H ? c->hdr.S + 2 : c->hdr.H;
-	if (const char* e = getenv("TD_RLE_CAP")) { const int v = atoi(e); if (v >= 1 && v <= 127) cap = v; }   // tests: force the overflow route
+	if (c->rle_cap_forced > 0) cap = c->rle_cap_forced;   // tests: force the overflow route
 	return cap;
 }
 
 // the decode kernel over a staged slot
-static int slot_decode(td_ctx* c, TdSlot& s, int mode)
+static int slot_decode(td_ctx* c, TdSlot& s, int mode, bool want_labels = true)
 {
 	if (!c->have_model) return fail(c, "td_run: no model uploaded");
 	if (mode != TD_MODE_GET_LABEL && mode != TD_MODE_GET_PROB && mode != TD_MODE_ARCH_COMP) return fail(c, "td_run: unsupported mode %d", mode);
 	if (!s.staged) return fail(c, "td_run: no batch resident (td_batch_upload failed or was not called)");
 	HIPCHK(c, hipSetDevice(c->device));
-	s.mode = mode; s.finished = false;
-	s.runs_cap = 0;   // (set again below when the specialised kernel leaves label runs: a batch through the generic kernel, or an
-	                  // empty one, must not hand the runs of this slot's previous batch to the finish kernel)
+	s.reset_decoded();   // (runs_cap above all: a launch of the generic kernel, or an empty batch, must not hand the label runs of this
+	                     // slot's previous launch to the finish kernel)
+	s.mode = mode;
 	if (s.n_tiles == 0) { s.ran = true; s.last_ms = 0.0f; return TD_OK; }
 	if (c->spec_ready && c->match_len > 0 && !c->spec_window) {   // first batch through a window: the kernel variant that applies it
 		HIPCHK(c, sync_compute(c));
@@ -1115,10 +1199,13 @@ static int slot_decode(td_ctx* c, TdSlot& s, int mode)
 		sa.ws = ka.ws; sa.lay = s.slay;
 		sa.lmax = s.n_big > 0 ? s.lmax_small : s.lmax;
 		sa.n_big = s.n_big; sa.lmax_big = s.lmax; sa.lay_big = s.slay_big; sa.out_lmax = s.lmax;
-		if (mode == TD_MODE_GET_LABEL) {   // the label runs for the compact egress, and the flag that says a read had more of them
+		// the label runs for the compact egress, and the flag that says a read had more of them -- only for a batch whose labels
+		// somebody will fetch (td_submit knows; a td_run batch may still be asked for them by td_batch_download)
+		if (mode == TD_MODE_GET_LABEL && want_labels && c->compact_egress) {
 			const int cap = rle_capacity(c);
 			const size_t words = (size_t)s.n_tiles * (size_t)cap * TD_WAVE + 1;
 			if (ensure(c, &s.d_runs, &s.cap_runs, words * 4) != TD_OK) return TD_FAIL;
+			if (c->poison) HIPCHK(c, hipMemsetAsync(s.d_runs, 0xFF, (words - 1) * 4, s.cs));   // (tests: a run the finish kernel reads must be this launch's)
 			HIPCHK(c, hipMemsetAsync(s.d_runs + words - 1, 0, 4, s.cs));
 			sa.out_runs = s.d_runs; sa.rle_overflow = (int32_t*)(s.d_runs + words - 1); sa.rle_cap = cap;
 			s.runs_cap = cap;
@@ -1172,8 +1259,8 @@ static int slot_issue_copies(td_ctx* c, TdSlot& s, hipStream_t down)
 static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* labels, uint8_t* seq_out, bool deferred)
 {
 	if (!s.ran) return fail(c, "td_batch_download: td_run has not been called on this batch");
+	s.reset_fetch();
 	s.u_res = res; s.u_labels = labels; s.u_seq = seq_out;
-	s.res_direct = s.lab_direct = s.seq_direct = false;
 	s.copies_deferred = deferred;
 	const int64_t n = s.n_reads;
 	if (n == 0) return TD_OK;
@@ -1183,7 +1270,7 @@ static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* l
 	// buffer was the DMA source, which the caller may have refilled since.  ri->labels is a handful of runs per read (the path
 	// moves through the segments in order): (length, label) pairs come back and the host expands them.  A fifth of the bytes
 	// over PCIe, and that much less work for the download's blit kernels, which compete with the decode kernel for CUs.
-	const bool compact = !(getenv("TD_COMPACT_EGRESS") && atoi(getenv("TD_COMPACT_EGRESS")) == 0);
+	const bool compact = c->compact_egress != 0;
 	s.use_keep = compact && seq_out && seq_bytes && !s.raw_direct && s.h_raw;
 	s.use_rle = compact && labels;
 	s.rle_cap = s.runs_cap > 0 ? s.runs_cap : rle_capacity(c);
@@ -1197,8 +1284,10 @@ static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* l
 	if (s.use_keep && (ensure(c, &s.d_keepo, &s.cap_keepo, keepo_bytes) != TD_OK || ensure_pinned(c, &s.h_keepo, &s.cap_h_keepo, keepo_bytes) != TD_OK)) return TD_FAIL;
 	if (s.use_rle) {
 		if (ensure(c, &s.d_rle, &s.cap_rle, rle_bytes) != TD_OK || ensure_pinned(c, &s.h_rle, &s.cap_h_rle, rle_bytes) != TD_OK) return TD_FAIL;
+		if (c->poison) HIPCHK(c, hipMemsetAsync(s.d_rle, 0xFF, (size_t)n * (size_t)s.rle_cap * 4, s.fin));   // (tests: every entry the host expands must be this batch's)
 		HIPCHK(c, hipMemsetAsync(s.d_rle + (size_t)n * (size_t)s.rle_cap, 0, 4, s.fin));   // the overflow flag
 	}
+	if (s.use_keep && c->poison) HIPCHK(c, hipMemsetAsync(s.d_keepo, 0xFF, keepo_bytes, s.fin));
 	s.sb.res = res ? s.d_res : nullptr;
 	s.sb.seq_out = (seq_out && !s.use_keep) ? s.d_seq : nullptr;
 	s.sb.labels_out = (labels && !s.use_rle) ? s.d_lab : nullptr;
@@ -1226,7 +1315,7 @@ static double wall_ms()
 static int slot_fetch_end(td_ctx* c, TdSlot& s)
 {
 	if (s.n_reads == 0 || !s.finished) return TD_OK;
-	const bool dbg = getenv("TD_DEBUG_WAIT") != nullptr;
+	const bool dbg = c->debug_wait != 0;
 	const double t0 = dbg ? wall_ms() : 0.0;
 	double t1 = t0;
 	if (s.copies_deferred) {
@@ -1328,8 +1417,9 @@ static int upload_common(td_ctx* c, const void* bases, int is_ascii, const int64
 	if (!c) return TD_FAIL;
 	if (tickets_outstanding(c)) return fail(c, "td_batch_upload: td_submit tickets are outstanding (td_wait them first)");
 	TdSlot& s = c->slots[0];
-	s.cs = c->stream; s.wsi = 0; s.aux = c->stream; s.fin = c->stream; s.pipelined = false;
-	if (slot_stage(c, s, bases, is_ascii, offs, n, c->stream) != TD_OK) return TD_FAIL;
+	TdRoute rt;
+	rt.cs = c->stream; rt.wsi = 0; rt.aux = c->stream; rt.fin = c->stream; rt.pipelined = false;
+	if (slot_stage(c, s, rt, bases, is_ascii, offs, n, c->stream) != TD_OK) return TD_FAIL;
 	HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller may reuse its buffers
 	c->last_slot = 0;
 	return TD_OK;
@@ -1391,15 +1481,16 @@ extern "C" int td_submit(td_ctx* c, const void* bases, int32_t is_ascii, const i
 	}
 	if (k < 0) return fail(c, "td_submit: all %d pipeline slots hold batches that have not been waited for", c->pipeline_depth);
 	TdSlot& s = c->slots[k];
-	s.cs = c->stream; s.wsi = 0; s.aux = c->stream; s.fin = c->stream; s.pipelined = true;
+	TdRoute rt;
+	rt.cs = c->stream; rt.wsi = 0; rt.aux = c->stream; rt.fin = c->stream; rt.pipelined = true;
 	if (c->overlap && c->pipeline_depth > 1 && c->spec_ready) {   // every other batch on the second stream / workspace
 		if (!c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-		if (c->submit_parity) { s.cs = c->stream2; s.wsi = 1; }
+		if (c->submit_parity) { rt.cs = c->stream2; rt.wsi = 1; }
 		c->submit_parity ^= 1;
-		s.aux = c->s_aux; s.fin = c->s_fin;
+		rt.aux = c->s_aux; rt.fin = c->s_fin;
 	}
-	if (slot_stage(c, s, bases, is_ascii != 0, offs, n_reads, c->s_up) != TD_OK) return TD_FAIL;
-	if (slot_decode(c, s, mode) != TD_OK) return TD_FAIL;
+	if (slot_stage(c, s, rt, bases, is_ascii != 0, offs, n_reads, c->s_up) != TD_OK) return TD_FAIL;
+	if (slot_decode(c, s, mode, labels != nullptr) != TD_OK) return TD_FAIL;
 	if (slot_fetch_begin(c, s, res, labels, seq_out, true) != TD_OK) return TD_FAIL;
 	// "returns once the reads have left the caller's buffers": a page-locked source is read by the DMA engine itself, so wait
 	// for that copy (a few ms at PCIe rate, beside the previous batch's kernel; everything of this batch is queued already)
@@ -1435,8 +1526,9 @@ extern "C" int td_arch_scores(td_ctx* c, const td_model_desc* const* models, int
 	HIPCHK(c, hipSetDevice(c->device));
 	TdSlot& s = c->slots[0];
 	// the reads are staged (sorted by length, packed) once; no model of the context is involved
-	s.cs = c->stream; s.wsi = 0; s.aux = c->stream; s.fin = c->stream;
-	if (slot_stage(c, s, codes, 0, offs, n_reads, c->stream, false) != TD_OK) return TD_FAIL;
+	TdRoute rt;
+	rt.cs = c->stream; rt.wsi = 0; rt.aux = c->stream; rt.fin = c->stream; rt.pipelined = false;
+	if (slot_stage(c, s, rt, codes, 0, offs, n_reads, c->stream, false) != TD_OK) return TD_FAIL;
 	s.staged = false;                      // not a batch td_run could use: it has no workspace geometry
 	if (s.n_tiles == 0) return TD_OK;
 	const int wpb = td_kernel_block_threads() / TD_WAVE;

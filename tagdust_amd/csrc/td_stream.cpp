@@ -136,6 +136,16 @@ public:
 		cv_.notify_all();
 		return true;
 	}
+	int try_pop(T& v)       // 1: got one; 0: nothing there right now; -1: closed and empty, or aborted
+	{
+		std::lock_guard<std::mutex> lk(mu_);
+		if (abort_) return -1;
+		if (q_.empty()) return closed_ ? -1 : 0;
+		v = std::move(q_.front());
+		q_.pop_front();
+		cv_.notify_all();
+		return 1;
+	}
 	void close() { std::lock_guard<std::mutex> lk(mu_); closed_ = true; cv_.notify_all(); }
 	void abort() { std::lock_guard<std::mutex> lk(mu_); abort_ = true; cv_.notify_all(); }
 
@@ -226,6 +236,13 @@ public:
 			if (r < 0) { if (errno == EINTR) continue; err = std::string("td_stream_run: read failed: ") + strerror(errno); return nullptr; }
 			if (r == 0) { end_of_input = true; break; }
 			have += r;
+		}
+		if (end_of_input && pipe_) {
+			// the decompressor's verdict: a truncated or corrupt .gz / .bz2 ends the stream early with a non-zero status -- an error,
+			// not the end of the input (io_handler's pclose, io.c:382-608, ignores it; a partial set of output files helps nobody)
+			const int status = pclose(pipe_);
+			pipe_ = nullptr;
+			if (status != 0) { err = "td_stream_run: the decompressor of the input file failed (status " + std::to_string(status) + "): truncated or corrupt input"; return nullptr; }
 		}
 		*read_s += now_s() - t0;
 		if (first_block_) { fasta_ = have > 0 && b->owned[0] == '>'; first_block_ = false; }
@@ -832,8 +849,15 @@ extern "C" int td_stream_run(td_ctx* ctx, const char* in_path, const td_arch* ar
 		p.st.decode_s += now_s() - t0;
 		return p.done->push(b);
 	};
-	Batch* b = nullptr;
-	while (rc == TD_OK && p.ready->pop(b)) {
+	// With nothing ready to submit and batches in flight the oldest one is retired instead of waiting: the reader may be waiting
+	// for exactly that batch's buffers.  (The allocator thread "runs with what it has" when page-locking fails part-way -- a
+	// memlock limit, a container -- and with fewer than depth + 2 batches in all a loop that only retires at full depth leaves
+	// the reader waiting for a free batch, this thread for a ready one and the writer for a finished one, forever.)
+	while (rc == TD_OK) {
+		Batch* b = nullptr;
+		const int got = flying.empty() ? (p.ready->pop(b) ? 1 : -1) : p.ready->try_pop(b);
+		if (got < 0) break;
+		if (got == 0) { if (!retire()) break; continue; }
 		if ((int)flying.size() >= depth && !retire()) break;
 		const double t0 = now_s();
 		if (ctx && td_submit(ctx, b->codes, 0, b->offs, b->n, TD_MODE_GET_LABEL, b->res, nullptr, b->seq_out, &b->ticket) != TD_OK) {

@@ -450,6 +450,14 @@ def stream_run(ctx, in_path, segments=None, out_prefix=None, batch_reads=0, n_th
             lib.td_arch_free(arch)
 
 
+def stream_release():
+    """td_stream_release: free the page-locked batch buffers td_stream_run keeps for the next run of the process (at most 1 GiB;
+    the library also frees them when the last context is destroyed)."""
+    lib = load_library()
+    lib.td_stream_release.restype = None
+    lib.td_stream_release()
+
+
 def spec_source(md):
     """The HIP source of the model-specialised kernel for this model (no GPU needed)."""
     lib = load_library()

@@ -368,7 +368,7 @@ def test_long_reads_switch_to_clamped_logsum(monkeypatch):
         c.set_option("specialize", 1)
         res0, labels0, seq0 = _run(c, g)
         assert c.get_option("spec_lsum_clamped") == 0
-        monkeypatch.setenv("TD_SPEC_LSUM_LIMIT", "1")
+        c.set_option("spec_lsum_limit", 1)      # (TD_SPEC_LSUM_LIMIT is read when a context is created)
         res1, labels1, seq1 = _run(c, g)
         assert c.get_option("spec_lsum_clamped") == 1
     finally:

@@ -100,6 +100,54 @@ def test_bounds_dominate_on_random_architectures(seed):
         assert rm.min() > 0.0, (segs, rm)
 
 
+def _long_reads(g, L, n, seed):
+    """Reads of ~L bases for the config-3 architecture, the kinds a long-read bound must survive: the architecture's own shape
+    with a long insert, inserts that take the read segment's maximum emission at every position (poly-base of the most frequent
+    background letter) or are all N, unrelated reads, N-rich reads, and ragged lengths around L."""
+    import bench
+    rng = np.random.RandomState(seed)
+    bg = np.asarray(g["bg"], np.float32)
+    top = int(np.argmax(bg[:4]))
+    bars = [[bench._CODE[c] for c in b] for b in bench.BARCODES]
+    head = lambda: np.array(bars[rng.randint(len(bars))] + [bench._CODE[c] for c in bench.SPACER], np.uint8)
+    ad = np.array([bench._CODE[c] for c in bench.ADAPTER], np.uint8)
+    reads = []
+    for k in range(n):
+        ll = L if k % 3 else int(L - rng.randint(0, max(2, L // 10)))
+        kind = k % 6
+        ins = rng.randint(0, 4, ll).astype(np.uint8)
+        if kind == 1:
+            ins[:] = top
+        elif kind == 2:
+            ins[:] = 4
+        elif kind == 3:
+            ins[rng.random_sample(ll) < 0.2] = 4
+        if kind != 4:                                 # (kind 4: an unrelated read)
+            h = head()
+            ins[:len(h)] = h
+            keep = rng.randint(0, len(ad) + 1)
+            if keep:
+                ins[ll - keep:] = ad[:keep]
+        reads.append(ins)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    return np.concatenate(reads), offs
+
+
+@pytest.mark.parametrize("L", [1000, 3000, 8000])
+def test_bounds_dominate_on_long_reads(L):
+    """Scores grow by ~1.4 nats per base, and half a float spacing per addition with them (2.4e-4 at |score| = 4096): the
+    bound tables carry a slack that grows with the magnitude of the bound (td_jit.hip row_slack / lse_up), so that they still
+    dominate every value of the oracle's matrices on reads of thousands of bases -- maximum-emission inserts included, for
+    which the bounds have no other slack.  Same for the starts of the restarted sweeps."""
+    g = load_golden("c3_b6_s_r_p")
+    seq, offs = _long_reads(g, L, 12, 4000 + L)
+    info, mg = _margins(g, seq, offs)
+    assert info["n_seg"] == 2 and info["sfx_first"] == 3
+    assert mg.min() > 0.0, (L, mg)
+    rm = _restart_margins(g, seq, offs)
+    assert rm.min() > 0.0, (L, rm)
+
+
 def test_model_section_states_the_pruned_segments():
     from tagdust_amd import lib as tdlib
     g = load_golden("c3_b6_s_r_p")
@@ -356,3 +404,49 @@ def test_restarted_sweeps_are_exact_or_fall_back(workload, n):
         assert d[206 - 192] == tiles and d[207 - 192] == 0 and d[238 - 192] == 0     # on by default, every bridge closes
     else:
         assert d[206 - 192] == 0                                                      # off for a handful of short HMMs (32 columns)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [1000, 3000, 8000])
+def test_long_reads_with_pruning_and_restarts_equal_the_oracle(L):
+    """Config 3's architecture on reads of 1000 / 3000 / 8000 bases with pruning and the restarted sweeps live (the bound
+    tables reach 8192 bases): maximum-emission (poly-base), all-N and N-rich inserts, unrelated reads, ragged lengths.  HIP ==
+    oracle bit for bit, and the statistics show that the pruned path (not a dense second pass) produced it."""
+    from oracle import pyoracle
+    from tagdust_amd import TagdustHip
+    g = load_golden("c3_b6_s_r_p")
+    n = 192 if L <= 3000 else 128
+    seq, offs = _long_reads(g, L, n, 5000 + L)
+    thr, minlen, dust = float(g["threshold"]), int(g["minlen"]), int(g["dust"])
+    ores, olab, oseq = pyoracle.label_batch(pyoracle.OracleModel(g), seq, offs, thr, minlen, dust, 8)
+    old = {k: os.environ.get(k) for k in ("TD_SPEC_PRUNE_STATS", "TD_NO_LENGTH_CLASSES")}
+    os.environ["TD_SPEC_PRUNE_STATS"] = "1"
+    try:
+        c = TagdustHip(0)
+        try:
+            c.set_option("poison_workspace", 1)
+            c.upload_model(g)
+            c.set_params(thr, minlen, dust)
+            c.upload_batch(seq, offs)
+            assert c.get_option("prune_active") == 1
+            c.counts_reset()
+            c.run()
+            res, labels, seq_after = c.download()
+            d = c.diag()
+        finally:
+            c.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for k in ("b_score", "f_score", "r_score", "bar_prob"):
+        assert np.array_equal(res[k].view(np.uint32), ores[k].view(np.uint32)), (k, L)
+    assert np.array_equal(labels, olab) and np.array_equal(seq_after, oseq)
+    assert np.allclose(res["mapq"], ores["Q"], rtol=0, atol=1e-4)
+    for k in ("read_type", "barcode", "fingerprint"):
+        assert np.array_equal(res[k], ores[k]), (k, L)
+    tiles = (n + 63) // 64
+    assert d[236 - 192] == tiles                       # every tile took the pruning decision ...
+    assert d[237 - 192] / tiles < 0.5 * L              # ... and the cut lies well inside the reads

@@ -98,6 +98,56 @@ def test_stream_errors_are_reported(tmp_path):
     assert st["n_reads"] == 0 and st["n_batches"] == 0
 
 
+def test_truncated_gz_is_an_error(tmp_path):
+    """A .gz cut short ends zcat with a non-zero status: the run fails instead of returning TD_OK on a partial input."""
+    from tagdust_amd import lib as tdlib
+    from tagdust_amd import TdError
+    gz = str(tmp_path / "cut.fq.gz")
+    with gzip.open(gz, "wb") as fh:
+        fh.write(_ugly_fastq(4000, 21))
+    data = open(gz, "rb").read()
+    open(gz, "wb").write(data[: len(data) // 2])
+    with pytest.raises(TdError, match="decompressor"):
+        tdlib.stream_run(None, gz, batch_reads=500, n_threads=2, block_bytes=8192)
+
+
+def test_pipeline_with_too_few_batch_buffers_does_not_hang(tmp_path):
+    """Page-locking can fail part-way (memlock limit, container): the helper thread that adds batch buffers then stops and the
+    pipeline runs with what it has.  With fewer batches than the in-flight depth + 2 it used to wait forever (reader for a free
+    batch, device thread for a ready one, writer for a finished one).  The streaming code as it is, device calls stubbed
+    (tools/tsan_stream/stub.cpp), the allocator cut off after N allocations: every N ends -- with the same files as an
+    unlimited run, or with the 'exhausted' error when not even one batch could be had."""
+    exe = str(tmp_path / "stream_stub")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(REPO, "include"), "-w", "-o", exe,
+                           os.path.join(REPO, "tools", "tsan_stream", "stub.cpp"), os.path.join(REPO, "tagdust_amd", "csrc", "td_stream.cpp"),
+                           os.path.join(REPO, "tagdust_amd", "csrc", "td_fastq.cpp")])
+    rng = np.random.RandomState(4)
+    fq = str(tmp_path / "in.fq")
+    with open(fq, "wb") as fh:
+        for i in range(20000):
+            L = int(rng.randint(20, 90))
+            fh.write(("@r%d\n%s\n+\n%s\n" % (i, "".join(rng.choice(list("ACGT"), L)), "I" * L)).encode())
+    os.makedirs("/tmp/td_tsan", exist_ok=True)       # (the stub's output prefix)
+
+    def run(limit):
+        env = dict(os.environ)
+        env.pop("TD_STUB_ALLOC_LIMIT", None)
+        if limit is not None:
+            env["TD_STUB_ALLOC_LIMIT"] = str(limit)
+        r = subprocess.run([exe, fq, "777", "2", "20000", "decode"], env=env, capture_output=True, timeout=120)   # a hang fails here
+        files = {os.path.basename(f): open(f, "rb").read() for f in sorted(glob.glob("/tmp/td_tsan/out*.fq"))}
+        return r.stdout.decode().splitlines()[0], files
+
+    want_line, want_files = run(None)
+    assert want_line.startswith("rc 0 reads 20000 ")
+    for limit in (4, 6, 8, 10, 12, 16, 20):
+        line, files = run(limit)
+        if line.startswith("rc 0"):
+            assert line == want_line and files == want_files, limit
+        else:
+            assert line.startswith("rc 1"), (limit, line)
+
+
 def test_rq_formatting_equals_printf():
     """The writer formats ";RQ:%0.2f" itself (float x 100 is exact in double, nearbyint rounds half to even like printf rounds
     the exact expansion).  Against C's printf (ctypes) on random floats of every magnitude a Q takes, on every tie k/200 +- 1 ulp,

@@ -121,6 +121,10 @@ def main():
                 rec["wait_any_share_of_wave_cycles"] = p.get("SQ_WAIT_ANY", 0) / p["SQ_WAVE_CYCLES"]
             if p.get("SQ_LDS_IDX_ACTIVE"):
                 rec["lds_bank_conflict_share"] = p.get("SQ_LDS_BANK_CONFLICT", 0) / p["SQ_LDS_IDX_ACTIVE"]
+                if p.get("GRBM_GUI_ACTIVE"):
+                    # SQ_LDS_IDX_ACTIVE sums LDS-array cycles over the 256 CUs; GRBM_GUI_ACTIVE sums the busy cycles of the 8 XCDs:
+                    # CU cycles of the launch = GRBM_GUI_ACTIVE / 8 x 256
+                    rec["lds_idx_active_share_of_cu_cycles"] = p["SQ_LDS_IDX_ACTIVE"] / (p["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)
             try:
                 sys.path.insert(0, os.path.join(REPO, "tools"))
                 import isa_report

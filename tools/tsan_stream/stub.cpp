@@ -4,7 +4,14 @@
 #include <stdio.h>
 // stand-ins for the device entry points (the parse-only run never calls them; a "decoding" run here returns zeroed results)
 extern "C" {
-void* td_host_alloc(size_t b) { return malloc(b ? b : 1); }
+// TD_STUB_ALLOC_LIMIT=N: the (N+1)-th and later page-locked allocations fail (a memlock limit met part-way)
+static int g_allocs = 0;
+void* td_host_alloc(size_t b)
+{
+	const char* e = getenv("TD_STUB_ALLOC_LIMIT");
+	if (e && __atomic_add_fetch(&g_allocs, 1, __ATOMIC_RELAXED) > atoi(e)) return nullptr;
+	return malloc(b ? b : 1);
+}
 void td_host_free(void* p) { free(p); }
 int td_get_option(td_ctx*, const char*, int32_t* v) { *v = 3; return 0; }
 const char* td_last_error(const td_ctx*) { return "stub"; }
