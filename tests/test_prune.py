@@ -392,11 +392,17 @@ def test_restarted_sweeps_are_exact_or_fall_back(workload, n):
     if workload != "c2":                                                   # (config 2 has no segment behind its read segment)
         assert d[198 - 192] == tiles and d[199 - 192] == 0                 # forward likewise
     assert d[238 - 192] == 0                                               # no dense second pass
-    short = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_RESTART": "1", "TD_SPEC_PRUNE_STATS": "1", "TD_SPEC_EXTRA_OPTS": "-DTDS_RESTART_W=2"})
+    short = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_RESTART": "1", "TD_SPEC_PRUNE_STATS": "1", "TD_SPEC_EXTRA_OPTS": "-DTDS_RESTART_W=2 -DTDS_RESTART_WMAX=2"})
     assert _same(dense, short)
     d = short[3]
     # every restarted tile failed to close and was decoded again without the restarts -- still pruned, not densely
     assert d[207 - 192] == tiles and d[238 - 192] == 0 and d[237 - 192] / tiles < 0.5 * (100 if workload == "c2" else 150)
+    # a wave whose bridges run out of positions widens their window before it gives the restarts up: from W = 2 every wave's
+    # first tile fails once or twice, the bridges then close, and no tile is decoded densely
+    widen = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_RESTART": "1", "TD_SPEC_PRUNE_STATS": "1", "TD_SPEC_EXTRA_OPTS": "-DTDS_RESTART_W=2"})
+    assert _same(dense, widen)
+    d = widen[3]
+    assert d[207 - 192] >= 1 and d[206 - 192] > d[207 - 192] and d[238 - 192] == 0
     default = _decode(workload, n, {"TD_SPEC_PRUNE": "1", "TD_SPEC_PRUNE_STATS": "1"})
     assert _same(dense, default)
     d = default[3]
