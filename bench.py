@@ -292,6 +292,70 @@ def e2e_stream(dev_index, copies=4, n=1 << 20, n_threads=0, keep_dir=None):
                     % (copies, n, st["n_batches"])}
 
 
+def write_casava_files(dirname, n, seed=11):
+    """BASELINE configs[3]: the reference's own index reads (dev/casava_read2.fastq.gz, kept as the fixture casava_index: 400
+    records with their CASAVA-1.8 names and qualities) tiled to n records with renumbered y coordinates, and the two missing
+    76-nt read files synthesised with matching names.  Returns (r1, r2, r3, the index file's segment list)."""
+    z = np.load(os.path.join(REPO, "tests", "golden", "casava_index.npz"))
+    names = bytes(z["names"]).split(b"\n")
+    offs, n0 = z["offs"], int(z["n_reads"])
+    alpha = np.frombuffer(b"ACGTN", np.uint8)
+    head, ycoord, s2, q2 = [], [], [], []
+    for j in range(n0):
+        parts = names[j].split(b" ")[0].split(b":")
+        head.append(b":".join(parts[:6]) + b":"); ycoord.append(int(parts[6]))
+        s2.append(bytes(alpha[z["seq"][offs[j]:offs[j + 1]]])); q2.append(bytes(z["qual"][offs[j]:offs[j + 1]]))
+    rng = np.random.default_rng(seed)
+    paths = [os.path.join(dirname, "r%d.fq" % k) for k in (1, 2, 3)]
+    qual = b"I" * 76
+    with open(paths[0], "wb") as f1, open(paths[1], "wb") as f2, open(paths[2], "wb") as f3:
+        for lo in range(0, n, 1 << 16):
+            hi = min(n, lo + (1 << 16))
+            bases = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (2, hi - lo, 76), dtype=np.uint8)]
+            o1, o2, o3 = [], [], []
+            for i in range(lo, hi):
+                j, t = i % n0, i // n0
+                base = head[j] + str(ycoord[j] + 100000 * t).encode()
+                o2.append(b"@" + base + b" 2:N:0:\n" + s2[j] + b"\n+\n" + q2[j] + b"\n")
+                # (now and then a low-complexity read in one of the plain files: run_rna_dust's DUST then decides the record's outcome)
+                b1 = b"A" * 76 if i % 97 == 5 else bases[0, i - lo].tobytes()
+                b3 = b"AC" * 38 if i % 101 == 7 else bases[1, i - lo].tobytes()
+                o1.append(b"@" + base + b" 1:N:0:\n" + b1 + b"\n+\n" + qual + b"\n")
+                o3.append(b"@" + base + b" 3:N:0:\n" + b3 + b"\n+\n" + qual + b"\n")
+            f1.write(b"".join(o1)); f2.write(b"".join(o2)); f3.write(b"".join(o3))
+    segs = [a for a in str(z["cmdline"]).split() if a.startswith("B:")]
+    return paths[0], paths[1], paths[2], segs
+
+
+def e2e_casava(dev_index, n=1 << 20, n_threads=0):
+    """BASELINE configs[3] at the library level: three input files in lock-step through td_stream_run_multi -- the index reads
+    decoded on the GPU (12 six-nt indexes + decoy), read 1 and read 3 not decoded (run_rna_dust), outcomes combined per record,
+    every read written to the index's file (src/barcode_hmm.c:244-385).  Model and threshold of the fixture; rate in records/s."""
+    import tempfile
+    from tagdust_amd import TagdustHip
+    from tagdust_amd import lib as tdlib
+    z = np.load(os.path.join(REPO, "tests", "golden", "casava_index.npz"))
+    model = {k: z[k] for k in z.files}
+    with tempfile.TemporaryDirectory() as tmp:
+        r1, r2, r3, segs = write_casava_files(tmp, n)
+        ctx = TagdustHip(dev_index)
+        try:
+            ctx.upload_model(model)
+            ctx.set_params(float(model["threshold"]), int(model["minlen"]), int(model["dust"]))
+            files = [(r2, segs, [ctx]), (r1, ["R:N"], None), (r3, ["R:N"], None)]
+            tdlib.stream_run_multi(files, os.path.join(tmp, "warm"), batch_reads=1 << 16, n_threads=n_threads)   # context warm, as in e2e_stream
+            st, cnt = tdlib.stream_run_multi(files, os.path.join(tmp, "out"), n_threads=n_threads)
+        finally:
+            ctx.close()
+    r = st["n_reads"]
+    return {"records": r, "input_files": 3, "batches": st["n_batches"], "fastq_bytes_in": st["bytes_in"], "fastq_bytes_out": st["bytes_out"],
+            "counters_add_up": bool(int(cnt[:8].sum()) == r), "extracted": int(cnt[0]), "wall_s": st["wall_s"],
+            "value": r / st["wall_s"] if st["wall_s"] > 0 else None, "unit": "records/s (one record = one read of each of the three files)",
+            "parse_busy_s": st["parse_s"], "write_busy_s": st["write_s"], "decode_thread_busy_s": st["decode_s"],
+            "what": "td_stream_run_multi on the CASAVA three-read shape (BASELINE configs[3]): %d records, index reads decoded on the GPU, "
+                    "two 76-nt read files written to the index's READ1 / READ2 files; model + threshold given, context warm" % r}
+
+
 class _DevCounters:
     """The library's device counters (td_counts_device_ptr) as a CUDA-array-interface object, so that torch can wrap them
     without a copy and RCCL reduces them in place."""
@@ -359,6 +423,8 @@ def measure_workload(name, n, steps, warmup, dev_index, specialize=1, depth=2, p
     ctx = TagdustHip(dev_index)
     ctx.set_option("specialize", specialize)
     ctx.set_option("pipeline_depth", depth)
+    if pinned:
+        ctx.set_option("stable_input", 1)     # the input buffers below are never refilled: page-locked input keeps the compact egress
     ctx.upload_model(model)
     ctx.set_params(float(model["threshold"]), 16, 100)
     rank = int(os.environ.get("RANK", "0"))
@@ -761,6 +827,10 @@ def main():
             extra["e2e"] = e2e_stream(dev_index)
         except Exception as e:      # the end-to-end extra must not take the bench line down
             extra["e2e"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            extra["config4"] = e2e_casava(dev_index)
+        except Exception as e:
+            extra["config4"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         out["extra"] = extra
         if args.cpu_sample and world == 1:

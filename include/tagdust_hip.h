@@ -118,7 +118,14 @@ int td_model_upload(td_ctx* ctx, const td_model_desc* model);
  * host threads of this context for its copies between pageable caller memory and pinned staging (started once, reused);  "overlap_decode" 1 (default; env TD_OVERLAP) = consecutive td_submit batches run their
  * decode kernels on two streams with a workspace each, so that one batch's kernel starts while the last one's slowest waves
  * finish (falls back to one stream when device memory cannot hold two workspaces);  "poison_workspace" 1 = fill the HBM workspace with 0xFF bytes before every decode launch
- * (tests: a kernel that reads workspace bytes it has not written in this launch then computes on NaNs). */
+ * (tests: a kernel that reads workspace bytes it has not written in this launch then computes on NaNs);
+ * "stable_input" 1 = the caller promises to leave a PAGE-LOCKED `bases` buffer handed to td_submit untouched until td_wait(ticket)
+ * has returned (default 0: it may be refilled as soon as td_submit returns).  With the promise td_submit does not wait for the upload
+ * and the rewritten sequences come back as keep bits that the host applies to the caller's own buffer (the compact egress) instead
+ * of as full device-side copies: the page-locked path then does strictly less host work and moves fewer bytes than the pageable one;
+ * "compact_egress" 1 (default; env TD_COMPACT_EGRESS) = rewritten sequences travel as keep bits, labels as runs;
+ * "length_classes_enabled" 1 (default; env TD_NO_LENGTH_CLASSES turns it off), "rle_cap", "debug_wait", "spec_lsum_limit" = test and
+ * diagnosis knobs.  Every environment variable is read once, when the context is created. */
 int td_set_option(td_ctx* ctx, const char* name, int32_t value);
 /* Read a setting back: "specialize", "pipeline_depth", "overlap_decode", or "spec_lsum_clamped" (1 when the loaded specialised kernel uses the clamped
  * logsum: the clamp-free form is only selected while model parameters x read length bound every score difference).
@@ -129,7 +136,11 @@ int td_set_option(td_ctx* ctx, const char* name, int32_t value);
  * is off, the pipeline is one deep, the generic kernel runs, or HBM could not hold the second workspace);
  * "artifacts_active" (1 while a -ref artifact filter is set, td_set_artifacts); "length_classes" (the number of wave slots
  * that were laid out for the last batch's longest read while the others kept the geometry of the reads at the 99 % mark --
- * a batch with a few very long reads among many short ones; 0: one geometry). */
+ * a batch with a few very long reads among many short ones; 0: one geometry);
+ * "hw_queues" (hardware queues of the HIP runtime as far as the library can tell: the user's GPU_MAX_HW_QUEUES, else the 8 the
+ * library asks for when it is loaded BEFORE the process's first HIP call, else the runtime's default 4) and "hw_queues_late" (1: the
+ * runtime was already initialised when the library was loaded, so its request had no effect -- set GPU_MAX_HW_QUEUES=8 in the
+ * environment instead; the pipelined calls keep six streams busy). */
 int td_get_option(td_ctx* ctx, const char* name, int32_t* value);
 /* The HIP source td_model_upload would compile for this model (no GPU needed).  Returns its length; copies at
  * most cap-1 bytes + NUL into buf when buf != NULL. */

@@ -94,6 +94,26 @@ typedef struct td_stream_stats {
 int td_format_q(float q, char* buf);
 int td_stream_run(td_ctx* ctx, const char* in_path, const td_arch* arch, const char* out_prefix,
                   const td_stream_opts* opts, td_stream_stats* stats);
+/* ---- several input files of one run, several devices (BASELINE configs[3]: the CASAVA three-read shape) ----
+ * The controller's loop for paired / multi-read data (hmm_controller_multiple, src/barcode_hmm.c:244-385): the next batch_reads
+ * records of EVERY input file (the files must hold the same reads in the same order: equal record counts, :257-268, and the first
+ * 1000 names compared like compare_read_names(), io.c:2128-2393) -> each file's records through that file's own model --
+ * run_pHMM's contiguous ranges (:1911-1922) over the n_devices contexts the caller holds for it, every range a td_submit /
+ * td_wait on its device, results in input order -- or, for a file whose architecture is a single read segment, through
+ * run_rna_dust (:315-319, :2370-2395: no HMM; DUST with `dust`, src/barcode_hmm.c:2407-2467) -> the per-record combination
+ * (:329-351: the outcome is the maximum over the files, the barcode that of the one file that has a barcode segment) ->
+ * print_all() (io.c:757-1016): every file that has read segments writes its records to its own "_READ<k>" files, named after the
+ * barcode file's architecture, by the combined outcome and barcode.  The same three-stage pipeline as td_stream_run, one
+ * reader / parser per input file.  counts (may be NULL) receives the controller's serial counting over the combined records
+ * (TD_NUM_COUNTERS words: outcome slots, then per-barcode bins).  A -ref artifact filter is not supported here. */
+typedef struct td_stream_file {
+	const char*    path;   /* one input file (plain, .gz, .bz2) */
+	const td_arch* arch;   /* its architecture: param->read_structures[i], barcode_hmm.c:105-137 */
+	td_ctx* const* ctx;    /* n_devices contexts holding this file's model, threshold, minlen and dust (one per device, in device
+	                          order); NULL for an architecture that is one read segment ("R:N"): that file is not decoded */
+} td_stream_file;
+int td_stream_run_multi(const td_stream_file* files, int32_t n_files, int32_t n_devices, const char* out_prefix, int32_t dust,
+                        const td_stream_opts* opts, td_stream_stats* stats, int64_t* counts /* [TD_NUM_COUNTERS] */);
 /* td_stream_run keeps the page-locked batch buffers of its last run (at most 1 GiB) for the next run of the process --
  * page-locking runs at about 1 GB/s, most of what a short file costs; this frees them. */
 void td_stream_release(void);

@@ -32,6 +32,14 @@ void td_shard_bounds(int64_t n_reads, int32_t world, int32_t rank, int64_t* lo, 
  * Adds to counts[TD_NUM_COUNTERS].  lens may be NULL (all reads counted). */
 void td_count_outcomes(const td_read_result* res, const int32_t* lens, int64_t n_reads, int64_t* counts);
 
+/* Diagnostic (tools/host_scale.py): the HOST halves of td_submit / td_wait for one batch of n_reads reads of read_len bases, run
+ * `iters` times back to back on n_threads threads WITHOUT a device -- the staging copy into page-locked memory, the records copy,
+ * the rebuilding of rewritten sequences from keep bits, the expansion of labels from runs: the very routines the library runs
+ * around its device calls.  mode 0: pageable caller buffers; 1: page-locked caller buffers under "stable_input".  out[0] = seconds
+ * per batch, out[1] = host bytes read + written per batch, out[2] = batches timed.  N processes of this side by side show what N
+ * ranks' host halves cost one host -- the ceiling the host sets for the 8-GPU run. */
+int td_host_halves_bench(int64_t n_reads, int32_t read_len, int32_t n_threads, int32_t iters, int32_t mode, double* out /* [3] */);
+
 /* Bind the calling host thread to the CPUs of the NUMA node next to `device` (as far as the process may use them); returns
  * the node, or -1 when it is unknown / none of its CPUs is available (the thread then stays where it is).  td_multi's
  * per-device threads call it; a one-process-per-GPU launcher calls it once per rank before it allocates host buffers. */

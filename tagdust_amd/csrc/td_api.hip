@@ -26,6 +26,7 @@
 #include "td_device.h"
 #include "td_jit.h"
 #include "td_stage.h"
+#include "td_host_inner.h"
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t td_launch_decode(const TdKernelArgs* ka, hipStream_t stream);   // library-internal
 extern "C" __attribute__((visibility("hidden"))) int td_kernel_block_threads(void);
@@ -72,6 +73,8 @@ struct TdStaged : TdRoute {
 	bool sorted = false;      // device order differs from the caller's (reads of several lengths)
 	bool staged = false;      // inputs are packed on the device: td_run may launch
 	bool raw_direct = false;  // the upload read the caller's page-locked buffer itself (no staging copy)
+	const uint8_t* raw_host = nullptr;   // the batch's bases on the host, valid until the batch has been waited for: the pinned staging
+	                                     // copy, or the caller's own page-locked buffer under the "stable_input" contract; else NULL
 	TdStageBatch sb{};
 	TdWsLayout lay{};
 	TdSpecLayout slay{};
@@ -173,81 +176,6 @@ __attribute__((constructor)) static void td_want_hw_queues()
 	if (!g_hwq_late) setenv("GPU_MAX_HW_QUEUES", "8", 0);
 }
 
-struct CopyPool {
-	struct Job { char* dst; const char* src; size_t bytes; const std::function<void(int64_t, int64_t)>* fn; int64_t lo, hi; };
-	std::vector<std::thread> th;
-	std::mutex mu;
-	std::condition_variable cv_job, cv_done;
-	std::deque<Job> q;
-	int pending = 0;
-	bool stop = false;
-
-	void start(int n_workers)
-	{
-		for (int k = (int)th.size(); k < n_workers; k++)
-			th.emplace_back([this] {
-				for (;;) {
-					Job j;
-					{
-						std::unique_lock<std::mutex> lk(mu);
-						cv_job.wait(lk, [this] { return stop || !q.empty(); });
-						if (q.empty()) return;   // stop
-						j = q.front(); q.pop_front();
-					}
-					if (j.fn) (*j.fn)(j.lo, j.hi); else memcpy(j.dst, j.src, j.bytes);
-					{
-						std::lock_guard<std::mutex> lk(mu);
-						if (--pending == 0) cv_done.notify_all();
-					}
-				}
-			});
-	}
-	// memcpy(dst, src, bytes) on nt threads (this one included)
-	void copy(void* dst, const void* src, size_t bytes, int nt)
-	{
-		const size_t chunk = (size_t)1 << 20;
-		const size_t nchunks = (bytes + chunk - 1) / chunk;
-		if ((size_t)nt > nchunks) nt = (int)nchunks;
-		if (nchunks <= 4 || nt <= 1) { memcpy(dst, src, bytes); return; }
-		start(nt - 1);
-		const size_t per = (nchunks + (size_t)nt - 1) / (size_t)nt * chunk;
-		{
-			std::lock_guard<std::mutex> lk(mu);
-			for (size_t lo = per; lo < bytes; lo += per) {
-				q.push_back(Job{ (char*)dst + lo, (const char*)src + lo, lo + per < bytes ? per : bytes - lo, nullptr, 0, 0 });
-				pending++;
-			}
-		}
-		cv_job.notify_all();
-		memcpy(dst, src, per < bytes ? per : bytes);
-		std::unique_lock<std::mutex> lk(mu);
-		cv_done.wait(lk, [this] { return pending == 0; });
-	}
-	// fn(lo, hi) over [0, n) in contiguous ranges on nt threads (this one included)
-	void ranges(int64_t n, int nt, const std::function<void(int64_t, int64_t)>& fn)
-	{
-		if (n <= 0) return;
-		if (nt > n / 4096) nt = (int)(n / 4096);
-		if (nt <= 1) { fn(0, n); return; }
-		start(nt - 1);
-		const int64_t per = (n + nt - 1) / nt;
-		{
-			std::lock_guard<std::mutex> lk(mu);
-			for (int64_t lo = per; lo < n; lo += per) { q.push_back(Job{ nullptr, nullptr, 0, &fn, lo, lo + per < n ? lo + per : n }); pending++; }
-		}
-		cv_job.notify_all();
-		fn(0, per < n ? per : n);
-		std::unique_lock<std::mutex> lk(mu);
-		cv_done.wait(lk, [this] { return pending == 0; });
-	}
-	~CopyPool()
-	{
-		{ std::lock_guard<std::mutex> lk(mu); stop = true; }
-		cv_job.notify_all();
-		for (auto& t : th) t.join();
-	}
-};
-
 struct td_ctx {
 	int device = 0;
 	int host_threads = default_host_threads();
@@ -304,6 +232,7 @@ struct td_ctx {
 	// development / test knobs: read from the environment ONCE, when the context is created (never on the per-batch path), and
 	// settable afterwards through td_set_option under the names in brackets
 	int compact_egress = 1;    // TD_COMPACT_EGRESS ["compact_egress"]: keep bits + label runs instead of plain copies
+	int stable_input = 0;      // ["stable_input"]: the caller leaves a page-locked input buffer alone until td_wait (see tagdust_hip.h)
 	int rle_cap_forced = 0;    // TD_RLE_CAP ["rle_cap"]: entries of the label-run table (0: S + 2)
 	int length_classes = 1;    // TD_NO_LENGTH_CLASSES ["length_classes_enabled"]
 	int debug_wait = 0;        // TD_DEBUG_WAIT ["debug_wait"]
@@ -714,6 +643,11 @@ extern "C" int td_set_option(td_ctx* c, const char* name, int32_t value)
 	}
 	if (!strcmp(name, "poison_workspace")) { c->poison = value != 0; return TD_OK; }
 	if (!strcmp(name, "compact_egress")) { c->compact_egress = value != 0; return TD_OK; }          // takes effect with the next download / td_submit
+	if (!strcmp(name, "stable_input")) {
+		if (tickets_outstanding(c)) return fail(c, "td_set_option: stable_input cannot change while tickets are outstanding");
+		c->stable_input = value != 0;
+		return TD_OK;
+	}
 	if (!strcmp(name, "length_classes_enabled")) { c->length_classes = value != 0; return TD_OK; }  // ... the next upload
 	if (!strcmp(name, "debug_wait")) { c->debug_wait = value != 0; return TD_OK; }
 	if (!strcmp(name, "spec_lsum_limit")) { c->lsum_limit = value > 0 ? (double)value : 1.0e6; return TD_OK; }   // tests; next upload
@@ -752,6 +686,7 @@ extern "C" int td_get_option(td_ctx* c, const char* name, int32_t* value)
 	if (!strcmp(name, "length_classes")) { *value = c->slots[c->last_slot].n_big; return TD_OK; }   // wave slots of the long geometry in the last batch
 	if (!strcmp(name, "overlap_decode")) { *value = c->overlap; return TD_OK; }
 	if (!strcmp(name, "compact_egress")) { *value = c->compact_egress; return TD_OK; }
+	if (!strcmp(name, "stable_input")) { *value = c->stable_input; return TD_OK; }
 	if (!strcmp(name, "length_classes_enabled")) { *value = c->length_classes; return TD_OK; }
 	// hardware queues of the HIP runtime as far as the library can tell (see td_want_hw_queues): the user's GPU_MAX_HW_QUEUES, else
 	// the 8 the library asked for when it was loaded before the runtime initialised, else the runtime's own default of 4
@@ -1104,6 +1039,9 @@ static int slot_stage(td_ctx* c, TdSlot& s, const TdRoute& route, const void* ba
 		if (ensure_pinned(c, &s.h_raw, &s.cap_h_raw, (size_t)n_bases) != TD_OK) return TD_FAIL;
 		parallel_copy(c, s.h_raw, src, (size_t)n_bases);
 		src = s.h_raw;
+		s.raw_host = s.h_raw;
+	} else if (n_bases > 0 && c->stable_input && s.pipelined) {
+		s.raw_host = (const uint8_t*)src;   // the caller's promise: untouched until td_wait -- the compact egress rebuilds from it
 	}
 	HIPCHK(c, hipMemcpyAsync(s.d_offs, s.h_offs, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, up));
 	if (n_bases > 0) HIPCHK(c, hipMemcpyAsync(s.d_raw, src, (size_t)n_bases, hipMemcpyHostToDevice, up));
@@ -1271,7 +1209,7 @@ static int slot_fetch_begin(td_ctx* c, TdSlot& s, td_read_result* res, int8_t* l
 	// moves through the segments in order): (length, label) pairs come back and the host expands them.  A fifth of the bytes
 	// over PCIe, and that much less work for the download's blit kernels, which compete with the decode kernel for CUs.
 	const bool compact = c->compact_egress != 0;
-	s.use_keep = compact && seq_out && seq_bytes && !s.raw_direct && s.h_raw;
+	s.use_keep = compact && seq_out && seq_bytes && s.raw_host != nullptr;
 	s.use_rle = compact && labels;
 	s.rle_cap = s.runs_cap > 0 ? s.runs_cap : rle_capacity(c);
 	if (res && ensure(c, &s.d_res, &s.cap_res, res_bytes) != TD_OK) return TD_FAIL;
@@ -1342,65 +1280,12 @@ static int slot_fetch_end(td_ctx* c, TdSlot& s)
 	if (s.u_res && !s.res_direct) parallel_copy(c, s.u_res, s.h_res, (size_t)n * sizeof(td_read_result));
 	if (s.u_seq && s.n_bases) {
 		if (s.use_keep) {
-			// make_extracted_read(), barcode_hmm.c:3343-3350, from the keep bits and the staged input (base codes as the device
-			// sees them: init_nuc_code for sequence text, anything above 4 is 4)
-			const int nw1 = s.nw1, ascii = s.is_ascii;
-			const uint8_t* raw = s.h_raw; const int64_t* offs = s.h_offs; const uint32_t* kb = s.h_keepo; uint8_t* out = s.u_seq;
-			static const struct Lut { uint8_t t[256]; Lut() { for (int k = 0; k < 256; k++) t[k] = 4; t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = t['U'] = t['u'] = 3; } } lut;
-			const std::function<void(int64_t, int64_t)> fn = [=](int64_t lo, int64_t hi) {
-				for (int64_t i = lo; i < hi; i++) {
-					const int64_t o = offs[i];
-					const int len = (int)(offs[i + 1] - o);
-					const uint32_t* kw = kb + i * nw1;
-					for (int p0 = 0; p0 < len; p0 += 32) {
-						const uint32_t w = kw[p0 >> 5];
-						const int e = len - p0 < 32 ? len - p0 : 32;
-						const uint8_t* src = raw + o + p0; uint8_t* dst = out + o + p0;
-						if (w == 0u) { memset(dst, 65, (size_t)e); continue; }
-						if (ascii) { for (int q = 0; q < e; q++) dst[q] = ((w >> q) & 1u) ? lut.t[src[q]] : (uint8_t)65; }
-						else {
-							// eight bases per step: the keep bits of the group spread into byte masks, kept bytes taken as they are
-							// (a group holding a code above 4 goes byte by byte)
-							int q = 0;
-							for (; q + 8 <= e; q += 8) {
-								uint64_t v;
-								memcpy(&v, src + q, 8);
-								if (((v + 0x7B7B7B7B7B7B7B7BULL) | v) & 0x8080808080808080ULL) break;
-								uint64_t m = ((uint64_t)((w >> q) & 0xFFu) * 0x0101010101010101ULL) & 0x8040201008040201ULL;
-								m = (((m + 0x7F7F7F7F7F7F7F7FULL) & 0x8080808080808080ULL) >> 7) * 0xFFULL;
-								v = (v & m) | (0x4141414141414141ULL & ~m);
-								memcpy(dst + q, &v, 8);
-							}
-							for (; q < e; q++) { const uint8_t cd = src[q] > 4 ? (uint8_t)4 : src[q]; dst[q] = ((w >> q) & 1u) ? cd : (uint8_t)65; }
-						}
-					}
-				}
-			};
-			c->pool.ranges(n, c->host_threads, fn);
+			td_host_rebuild_sequences(c->pool, c->host_threads, n, s.raw_host, s.h_offs, s.h_keepo, s.nw1, s.is_ascii, s.u_seq);
 		} else if (!s.seq_direct) parallel_copy(c, s.u_seq, s.h_seq, (size_t)s.n_bases);
 	}
 	if (s.u_labels) {
 		if (s.use_rle) {
-			const int cap = s.rle_cap;
-			const int64_t* offs = s.h_offs; const uint32_t* rl = s.h_rle; int8_t* out = s.u_labels;
-			const std::function<void(int64_t, int64_t)> fn = [=](int64_t lo, int64_t hi) {
-				for (int64_t i = lo; i < hi; i++) {
-					int8_t* p = out + offs[i] + i;
-					int8_t* const end = out + offs[i + 1] + i + 1;   // the read's len + 1 labels
-					const uint32_t* r = rl + i * cap;
-					for (int j = 0; j < cap && r[j]; j++) {
-						// a run in 8-byte stores that may run over into the next run of the same read (written after it), never
-						// past the read's own labels
-						const size_t len = r[j] >> 8;
-						const uint64_t pat = (uint64_t)(r[j] & 0xFF) * 0x0101010101010101ULL;
-						size_t k = 0;
-						for (; k < len && p + k + 8 <= end; k += 8) memcpy(p + k, &pat, 8);
-						for (; k < len; k++) p[k] = (int8_t)(r[j] & 0xFF);
-						p += len;
-					}
-				}
-			};
-			c->pool.ranges(n, c->host_threads, fn);
+			td_host_expand_labels(c->pool, c->host_threads, n, s.h_offs, s.h_rle, s.rle_cap, s.u_labels);
 		} else if (!s.lab_direct) parallel_copy(c, s.u_labels, s.h_lab, (size_t)(s.n_bases + n));
 	}
 	return TD_OK;
@@ -1494,7 +1379,7 @@ extern "C" int td_submit(td_ctx* c, const void* bases, int32_t is_ascii, const i
 	if (slot_fetch_begin(c, s, res, labels, seq_out, true) != TD_OK) return TD_FAIL;
 	// "returns once the reads have left the caller's buffers": a page-locked source is read by the DMA engine itself, so wait
 	// for that copy (a few ms at PCIe rate, beside the previous batch's kernel; everything of this batch is queued already)
-	if (s.raw_direct) HIPCHK(c, hipEventSynchronize(s.ev_up));
+	if (s.raw_direct && !c->stable_input) HIPCHK(c, hipEventSynchronize(s.ev_up));
 	s.ticket = ++c->ticket_counter;
 	c->next_slot = (k + 1) % c->pipeline_depth;
 	*ticket = s.ticket;

@@ -195,11 +195,18 @@ struct td_writer {
 
 void td_writer_file_names(const char* prefix, const td_arch* a, std::vector<std::string>& names, int* num_alternatives)
 {
+	td_writer_file_names_n(prefix, a, -1, names, num_alternatives);
+}
+
+// n_out_reads: read segments over ALL input files of the run (io.c:795-797: num_out_reads); < 0: those of this architecture
+void td_writer_file_names_n(const char* prefix, const td_arch* a, int n_out_reads, std::vector<std::string>& names, int* num_alternatives)
+{
 	int barsegment = -1, n_r = 0;
 	for (int i = 0; i < a->n_segments; i++) {
 		if (a->type[i] == 'B' && barsegment < 0) barsegment = i;
 		if (a->type[i] == 'R') n_r++;
 	}
+	if (n_out_reads >= 0) n_r = n_out_reads;
 	const int alt = barsegment >= 0 ? a->n_seq[barsegment] : 2;
 	if (num_alternatives) *num_alternatives = alt;
 	names.clear();

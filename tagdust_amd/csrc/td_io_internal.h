@@ -19,5 +19,6 @@ int64_t td_next_record_start(const char* text, int64_t len, int64_t from, bool f
 extern const uint8_t* const td_nuc_code_ptr;   // [256]
 // print_all()'s file set for one input file (src/io.c:859-915): names in file-index order; *num_alternatives as io.c:923-934 uses it
 void td_writer_file_names(const char* prefix, const td_arch* a, std::vector<std::string>& names, int* num_alternatives);
+void td_writer_file_names_n(const char* prefix, const td_arch* a, int n_out_reads, std::vector<std::string>& names, int* num_alternatives);
 // "td_..." message of the last failure on this thread (td_io_last_error)
 void td_io_set_error(const std::string& msg);

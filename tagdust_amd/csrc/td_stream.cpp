@@ -294,6 +294,7 @@ struct Batch {
 	int64_t ticket = 0;
 	bool last = false;
 	int64_t cap_reads = 0;      // offs / res hold this many reads
+	const uint8_t* seq_src = nullptr;   // what the writer prints: seq_out, or codes for a file that is not decoded (run_rna_dust)
 };
 
 // Page-locked batch buffers outlive a run: page-locking runs at about 1 GB/s, which is most of what a short file costs.  The
@@ -422,7 +423,10 @@ inline int64_t span_of(const uint8_t* s, int64_t n) { int64_t g = 0; while (g < 
 inline void codes_to_text(char* w, const uint8_t* s, size_t n) { static const char alphabet[] = "ACGTNN"; for (size_t k = 0; k < n; k++) w[k] = alphabet[s[k]]; }
 #endif
 
-void format_records(const Batch& b, const Piece& pc, int64_t lo, int64_t hi, int num_alternatives, OutBufs& out)
+// ctype / cbar: read_type and barcode of the record as the controller combines them over the input files of a run
+// (barcode_hmm.c:329-351; NULL: this file's own); file_base: index of this input file's first output file (io.c:917-1001: c)
+void format_records(const Batch& b, const Piece& pc, int64_t lo, int64_t hi, int num_alternatives, OutBufs& out,
+                    const int32_t* ctype = nullptr, const int32_t* cbar = nullptr, size_t file_base = 0)
 {
 	const char* text = pc.blk->data;
 	const std::vector<TdRec>& recs = *pc.recs;
@@ -433,9 +437,11 @@ void format_records(const Batch& b, const Piece& pc, int64_t lo, int64_t hi, int
 		const int64_t i = pc.first + (r - pc.lo);             // index in the batch
 		const td_read_result& rr = b.res[i];
 		size_t f;                                              // io.c:923-934
-		if (rr.read_type == TD_EXTRACT_SUCCESS) f = (rr.barcode != -1) ? (size_t)(rr.barcode & 0xFF) : 0;
+		const int32_t rtype = ctype ? ctype[i] : rr.read_type, rbar = cbar ? cbar[i] : rr.barcode;
+		if (rtype == TD_EXTRACT_SUCCESS) f = (rbar != -1) ? (size_t)(rbar & 0xFF) : 0;
 		else f = (size_t)num_alternatives - 1;
-		const uint8_t* s = b.seq_out + b.offs[i];
+		f += file_base;
+		const uint8_t* s = (b.seq_src ? b.seq_src : b.seq_out) + b.offs[i];
 		const int64_t len = b.offs[i + 1] - b.offs[i];
 		const char* q = rec.qual_off >= 0 ? text + rec.qual_off : nullptr;
 		int head_len = -1;
@@ -682,77 +688,85 @@ struct Pipeline {
 		ready->close();
 	}
 
+	// format the records of one batch per output file (on the write pool) and append them in input order
+	bool write_batch(Batch* b, std::vector<OutBufs>& bufs, const int32_t* ctype, const int32_t* cbar, size_t file_base)
+	{
+		const double t0 = now_s();
+		const int W = write_pool->size();
+		struct Sub { size_t piece; int64_t lo, hi; };
+		std::vector<Sub> subs;
+		const int64_t step = std::max<int64_t>(4096, (b->n + W * 4 - 1) / (W * 4));
+		for (size_t p = 0; p < b->pieces.size(); p++)
+			for (int64_t a = b->pieces[p].lo; a < b->pieces[p].hi; a += step)
+				subs.push_back(Sub{ p, a, std::min<int64_t>(a + step, b->pieces[p].hi) });
+		if (bufs.size() < subs.size()) bufs.resize(subs.size());
+		for (size_t k = 0; k < subs.size(); k++) {
+			if (bufs[k].file.size() != fds.size()) bufs[k].file.resize(fds.size());
+			for (auto& s : bufs[k].file) s.n = 0;
+		}
+		write_pool->run((int64_t)subs.size(), [&](int64_t k) {
+			const Sub& sb = subs[(size_t)k];
+			format_records(*b, b->pieces[sb.piece], sb.lo, sb.hi, num_alternatives, bufs[(size_t)k], ctype, cbar, file_base);
+		});
+		dbg_format += now_s() - t0;
+		// Appends.  Buffered writes to one file serialise on its inode lock (8 threads on one file: 8 GB/s; one thread on each of
+		// nine files: 56 GB/s, tools/ubench/file_write.cpp), so a file gets one task that appends its share of every sub-range
+		// in order -- or a few tasks over runs of sub-ranges when it takes most of the bytes (no barcode segment: two files)
+		struct Wr { size_t file, k0, k1; int64_t at; };
+		std::vector<Wr> wr;
+		int64_t total_bytes = 0;
+		std::vector<int64_t> per_file(fds.size(), 0);
+		for (size_t f = 0; f < fds.size(); f++) {
+			for (size_t k = 0; k < subs.size(); k++) per_file[f] += (int64_t)bufs[k].file[f].n;
+			total_bytes += per_file[f];
+		}
+		for (size_t f = 0; f < fds.size(); f++) {
+			if (!per_file[f]) continue;
+			int parts = (int)((double)per_file[f] / (double)total_bytes * (double)W + 0.5);
+			if (parts > 4) parts = 4;
+			if (parts < 1) parts = 1;
+			const int64_t target = (per_file[f] + parts - 1) / parts;
+			int64_t at = file_off[f], acc = 0;
+			size_t k0 = 0;
+			for (size_t k = 0; k < subs.size(); k++) {
+				acc += (int64_t)bufs[k].file[f].n;
+				if (acc >= target || k + 1 == subs.size()) {
+					if (acc > 0) wr.push_back(Wr{ f, k0, k + 1, at });
+					at += acc; acc = 0; k0 = k + 1;
+				}
+			}
+			file_off[f] += per_file[f];
+			st.bytes_out += per_file[f];
+		}
+		std::vector<int> wrc(wr.size(), 0);
+		write_pool->run((int64_t)wr.size(), [&](int64_t t) {
+			const Wr& w = wr[(size_t)t];
+			int64_t at = w.at;
+			for (size_t k = w.k0; k < w.k1; k++) {
+				const Bytes& s = bufs[k].file[w.file];
+				size_t off = 0;
+				while (off < s.n) {
+					const ssize_t r = pwrite(fds[w.file], s.p + off, s.n - off, (off_t)(at + (int64_t)off));
+					if (r < 0) { if (errno == EINTR) continue; wrc[(size_t)t] = errno ? errno : EIO; return; }
+					off += (size_t)r;
+				}
+				at += (int64_t)s.n;
+			}
+		});
+		dbg_pwrite = dbg_pwrite + (now_s() - t0);
+		for (int e : wrc) if (e) { fail(std::string("td_stream_run: write failed: ") + strerror(e)); return false; }
+		return true;
+	}
+
 	// ---- stage 3: format the records per output file and append them in input order ----
 	void consumer()
 	{
 		Batch* b = nullptr;
-		const int W = write_pool->size();
 		std::vector<OutBufs> bufs;
 		while (done->pop(b)) {
 			const double t0 = now_s();
 			if (!dry) {
-				struct Sub { size_t piece; int64_t lo, hi; };
-				std::vector<Sub> subs;
-				const int64_t step = std::max<int64_t>(4096, (b->n + W * 4 - 1) / (W * 4));
-				for (size_t p = 0; p < b->pieces.size(); p++)
-					for (int64_t a = b->pieces[p].lo; a < b->pieces[p].hi; a += step)
-						subs.push_back(Sub{ p, a, std::min<int64_t>(a + step, b->pieces[p].hi) });
-				if (bufs.size() < subs.size()) bufs.resize(subs.size());
-				for (size_t k = 0; k < subs.size(); k++) {
-					if (bufs[k].file.size() != fds.size()) bufs[k].file.resize(fds.size());
-					for (auto& s : bufs[k].file) s.n = 0;
-				}
-				write_pool->run((int64_t)subs.size(), [&](int64_t k) {
-					const Sub& sb = subs[(size_t)k];
-					format_records(*b, b->pieces[sb.piece], sb.lo, sb.hi, num_alternatives, bufs[(size_t)k]);
-				});
-				dbg_format += now_s() - t0;
-				// Appends.  Buffered writes to one file serialise on its inode lock (8 threads on one file: 8 GB/s; one thread on each of
-				// nine files: 56 GB/s, tools/ubench/file_write.cpp), so a file gets one task that appends its share of every sub-range
-				// in order -- or a few tasks over runs of sub-ranges when it takes most of the bytes (no barcode segment: two files)
-				struct Wr { size_t file, k0, k1; int64_t at; };
-				std::vector<Wr> wr;
-				int64_t total_bytes = 0;
-				std::vector<int64_t> per_file(fds.size(), 0);
-				for (size_t f = 0; f < fds.size(); f++) {
-					for (size_t k = 0; k < subs.size(); k++) per_file[f] += (int64_t)bufs[k].file[f].n;
-					total_bytes += per_file[f];
-				}
-				for (size_t f = 0; f < fds.size(); f++) {
-					if (!per_file[f]) continue;
-					int parts = (int)((double)per_file[f] / (double)total_bytes * (double)W + 0.5);
-					if (parts > 4) parts = 4;
-					if (parts < 1) parts = 1;
-					const int64_t target = (per_file[f] + parts - 1) / parts;
-					int64_t at = file_off[f], acc = 0;
-					size_t k0 = 0;
-					for (size_t k = 0; k < subs.size(); k++) {
-						acc += (int64_t)bufs[k].file[f].n;
-						if (acc >= target || k + 1 == subs.size()) {
-							if (acc > 0) wr.push_back(Wr{ f, k0, k + 1, at });
-							at += acc; acc = 0; k0 = k + 1;
-						}
-					}
-					file_off[f] += per_file[f];
-					st.bytes_out += per_file[f];
-				}
-				std::vector<int> wrc(wr.size(), 0);
-				write_pool->run((int64_t)wr.size(), [&](int64_t t) {
-					const Wr& w = wr[(size_t)t];
-					int64_t at = w.at;
-					for (size_t k = w.k0; k < w.k1; k++) {
-						const Bytes& s = bufs[k].file[w.file];
-						size_t off = 0;
-						while (off < s.n) {
-							const ssize_t r = pwrite(fds[w.file], s.p + off, s.n - off, (off_t)(at + (int64_t)off));
-							if (r < 0) { if (errno == EINTR) continue; wrc[(size_t)t] = errno ? errno : EIO; return; }
-							off += (size_t)r;
-						}
-						at += (int64_t)s.n;
-					}
-				});
-				dbg_pwrite = dbg_pwrite + (now_s() - t0);
-				for (int e : wrc) if (e) { fail(std::string("td_stream_run: write failed: ") + strerror(e)); return; }
+				if (!write_batch(b, bufs, nullptr, nullptr, 0)) return;
 			} else {
 				// parse-only run: a checksum over what would have gone to the device (lengths and codes, in order)
 				for (int64_t i = 0; i < b->n; i++) {
@@ -770,6 +784,25 @@ struct Pipeline {
 		if (getenv("TD_STREAM_DEBUG")) fprintf(stderr, "td_stream: formatting %.3f s, appends %.3f s (write stage %.3f s)\n", dbg_format, dbg_pwrite - dbg_format, st.write_s);
 	}
 };
+
+// the batches of a finished run: kept for the next one (page-locked, within the cache's size) or freed
+static void release_batches(Pipeline& p, bool keep)
+{
+	std::lock_guard<std::mutex> lk(g_cache_mu);
+	size_t held = 0;
+	for (const Batch* q : g_cache) held += batch_bytes(q);
+	for (Batch* q : p.all) {
+		if (!p.dry && keep && q->codes && held + batch_bytes(q) <= kCacheBytes) {
+			q->pieces.clear(); q->n = 0; q->n_bases = 0; q->ticket = 0; q->seq_src = nullptr;
+			held += batch_bytes(q);
+			g_cache.push_back(q);
+			continue;
+		}
+		buf_free(p.dry, q->codes); buf_free(p.dry, q->seq_out); buf_free(p.dry, q->offs); buf_free(p.dry, q->res);
+		delete q;
+	}
+	p.all.clear();
+}
 
 } // namespace
 
@@ -877,24 +910,327 @@ extern "C" int td_stream_run(td_ctx* ctx, const char* in_path, const td_arch* ar
 	p.free_list->abort();          // (an allocator waiting to hand over a batch)
 	t_alloc.join();
 	for (int fd : p.fds) if (close(fd) != 0 && !p.failed()) p.fail(std::string("td_stream_run: close failed: ") + strerror(errno));
-	{
-		std::lock_guard<std::mutex> lk(g_cache_mu);
-		size_t held = 0;
-		for (const Batch* q : g_cache) held += batch_bytes(q);
-		for (Batch* q : p.all) {
-			if (!p.dry && !p.failed() && q->codes && held + batch_bytes(q) <= kCacheBytes) {
-				q->pieces.clear(); q->n = 0; q->n_bases = 0; q->ticket = 0;
-				held += batch_bytes(q);
-				g_cache.push_back(q);
-				continue;
-			}
-			buf_free(p.dry, q->codes); buf_free(p.dry, q->seq_out); buf_free(p.dry, q->offs); buf_free(p.dry, q->res);
-			delete q;
-		}
-	}
+	release_batches(p, !p.failed());
 	p.st.wall_s = now_s() - t_start;
 	p.st.codes_fnv = p.dry ? p.fnv : 0;
 	if (stats) *stats = p.st;
 	if (p.failed()) { td_io_set_error(p.err); return TD_FAIL; }
 	return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Several input files of one run, several devices: the controller's loop for paired / three-read data
+// (hmm_controller_multiple, src/barcode_hmm.c:244-385).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+// dust_sequences(), src/barcode_hmm.c:2407-2467, on a read that nothing was removed from (run_rna_dust: the read as it was read)
+bool rna_dust_low(const uint8_t* s, int64_t len, int dust_cut)
+{
+	if (len < 1) return false;
+	int trip[64];
+	for (int j = 0; j < 64; j++) trip[j] = 0;
+	auto at = [&](int64_t k) -> unsigned { return k < len ? (unsigned)s[k] : 0u; };   // (the reference's sequences end in a 0 byte)
+	unsigned key = ((at(0) & 3u) << 2) | (at(1) & 3u);
+	const int64_t n = len > 64 ? 64 : len;
+	int64_t c = 2;
+	for (int64_t j = 2; j < n; j++) {
+		key = ((key << 2) | (at(j) & 3u)) & 0x3Fu;
+		trip[key]++;
+		c++;
+	}
+	double sc = 0.0;
+	for (int j = 0; j < 64; j++) sc += (double)trip[j] * ((double)trip[j] - 1.0) / 2.0;
+	sc = sc / (double)(c - 3) * 10.0;
+	return sc > (double)dust_cut;
+}
+
+// compare_read_names(), src/io.c:2128-2393: the same place on the flow cell (CASAVA 1.8 / <= 1.7 names), else the same name up
+// to the first blank or ';'.  The format is taken from the first name seen (`detected`, like the reference's static).
+bool names_differ(const std::string& a, const std::string& b, int& detected)
+{
+	char i1[100], f1[100], i2[100], f2[100];
+	int r1 = 0, l1 = 0, t1 = 0, x1 = 0, y1 = 0, r2 = 0, l2 = 0, t2 = 0, x2 = 0, y2 = 0;
+	i1[0] = f1[0] = i2[0] = f2[0] = 0;
+	if (detected == -1) {
+		if (sscanf(a.c_str(), "%99[^:]:%d:%99[^:]:%d:%d:%d:%d ", i1, &r1, f1, &l1, &t1, &x1, &y1) == 7) detected = 1;
+		else if (sscanf(a.c_str(), "%99[^:]:%d:%d:%d:%d", i1, &l1, &t1, &x1, &y1) == 5) detected = 2;
+		else detected = 1000;
+	}
+	if (detected == 1) {
+		if (sscanf(a.c_str(), "%99[^:]:%d:%99[^:]:%d:%d:%d:%d ", i1, &r1, f1, &l1, &t1, &x1, &y1) != 7) return true;
+		if (sscanf(b.c_str(), "%99[^:]:%d:%99[^:]:%d:%d:%d:%d ", i2, &r2, f2, &l2, &t2, &x2, &y2) != 7) return true;
+		return y1 != y2 || x1 != x2 || t1 != t2 || l1 != l2 || strcmp(f1, f2) != 0 || r1 != r2 || strcmp(i1, i2) != 0;
+	}
+	if (detected == 2) {
+		if (sscanf(a.c_str(), "%99[^:]:%d:%d:%d:%d", i1, &l1, &t1, &x1, &y1) != 5) return true;
+		if (sscanf(b.c_str(), "%99[^:]:%d:%d:%d:%d", i2, &l2, &t2, &x2, &y2) != 5) return true;
+		return y1 != y2 || x1 != x2 || t1 != t2 || l1 != l2 || strcmp(i1, i2) != 0;
+	}
+	for (size_t i = 0; i < a.size(); i++) {
+		if (isspace((unsigned char)a[i]) || a[i] == ';') break;
+		if (i >= b.size() || a[i] != b[i]) return true;
+	}
+	return false;
+}
+
+// name of record i of a batch
+std::string record_name(const Batch& b, int64_t i)
+{
+	for (const Piece& pc : b.pieces)
+		if (i >= pc.first && i < pc.first + (pc.hi - pc.lo)) {
+			const TdRec& r = (*pc.recs)[(size_t)(pc.lo + (i - pc.first))];
+			return std::string(pc.blk->data + r.name_off, (size_t)r.name_len);
+		}
+	return std::string();
+}
+
+struct Tuple {                        // record range [k * batch_reads, ...) of every input file
+	std::vector<Batch*> b;
+	std::vector<std::vector<int64_t>> tickets;   // [file][device]
+};
+
+} // namespace
+
+extern "C" int td_stream_run_multi(const td_stream_file* files, int32_t n_files, int32_t n_devices, const char* out_prefix, int32_t dust,
+                                   const td_stream_opts* opts, td_stream_stats* stats, int64_t* counts)
+{
+	if (!files || n_files < 1 || n_files > 8 || !out_prefix) { td_io_set_error("td_stream_run_multi: bad arguments (1..8 input files, an output prefix)"); return TD_FAIL; }
+	if (n_devices < 1) n_devices = 1;
+	const int K = n_files, N = n_devices;
+	// barcode_hmm.c:105-153: which file holds the barcode (at most one may), how many read segments every file contributes
+	int bar_file = -1, num_out_reads = 0;
+	std::vector<int> read_present((size_t)K, 0);
+	for (int k = 0; k < K; k++) {
+		const td_arch* a = files[k].arch;
+		if (!files[k].path || !a || a->n_segments < 1) { td_io_set_error("td_stream_run_multi: every input file needs a path and an architecture"); return TD_FAIL; }
+		bool has_bar = false;
+		for (int j = 0; j < a->n_segments; j++) { if (a->type[j] == 'B') has_bar = true; if (a->type[j] == 'R') read_present[(size_t)k]++; }
+		if (has_bar) {
+			if (bar_file >= 0) { td_io_set_error("td_stream_run_multi: barcodes seem to be in both architectures (barcode_hmm.c:140-145)"); return TD_FAIL; }
+			bar_file = k;
+		}
+		num_out_reads += read_present[(size_t)k];
+		if (!files[k].ctx) {
+			// run_rna_dust (barcode_hmm.c:315-319) is what the controller runs instead of the HMM for an architecture that is one read segment
+			if (!(a->n_segments == 1 && a->type[0] == 'R')) { td_io_set_error("td_stream_run_multi: a file without contexts must have the architecture R:N"); return TD_FAIL; }
+		} else {
+			for (int d = 0; d < N; d++) if (!files[k].ctx[d]) { td_io_set_error("td_stream_run_multi: NULL context"); return TD_FAIL; }
+			int32_t art = 0;
+			(void)td_get_option(files[k].ctx[0], "artifacts_active", &art);
+			if (art) { td_io_set_error("td_stream_run_multi: a -ref artifact filter is not supported here (its thread ranges belong to the reference's batches; use td_stream_run / td_multi_decode)"); return TD_FAIL; }
+		}
+	}
+	if (num_out_reads == 0) { td_io_set_error("td_stream_run_multi: no read segment in any architecture: no output files to create (io.c:846-852)"); return TD_FAIL; }
+	// print_all() names its files after param->read_structure: the barcode file's architecture, else the last file's
+	const td_arch* print_arch = files[bar_file >= 0 ? bar_file : K - 1].arch;
+	td_stream_opts o{};
+	if (opts) o = *opts;
+	if (o.batch_reads <= 0) o.batch_reads = 1 << 18;
+	if (o.block_bytes <= 0) o.block_bytes = (int64_t)64 << 20;
+	if (o.block_bytes < 4096) o.block_bytes = 4096;
+	int hw = (int)std::thread::hardware_concurrency();
+	if (hw < 1) hw = 1;
+	if (o.n_threads <= 0) o.n_threads = hw >= 16 ? 8 : (hw >= 4 ? hw / 2 : 1);
+	if (o.n_threads > 32) o.n_threads = 32;
+	int32_t depth = 3;
+	for (int k = 0; k < K; k++) if (files[k].ctx) { (void)td_get_option(files[k].ctx[0], "pipeline_depth", &depth); break; }
+	const double t_start = now_s();
+
+	// the writer's side lives in one Pipeline object (output files, write pool, statistics), the readers' in one per input file
+	Pipeline pw;
+	pw.o = o; pw.dry = false;
+	std::vector<std::unique_ptr<Pipeline>> pf;
+	for (int k = 0; k < K; k++) pf.emplace_back(new Pipeline());
+	const int n_batches = depth + 4;
+	auto fail_all = [&](const std::string& m) { pw.fail(m); for (auto& q : pf) q->fail(m); };
+	pw.ready.reset(new Queue<Batch*>(1)); pw.done.reset(new Queue<Batch*>(1)); pw.free_list.reset(new Queue<Batch*>(1));
+	{
+		std::vector<std::string> names;
+		td_writer_file_names_n(out_prefix, print_arch, num_out_reads, names, &pw.num_alternatives);
+		for (auto& nm : names) {
+			const int fd = open(nm.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+			if (fd < 0) { for (int g : pw.fds) close(g); td_io_set_error("td_stream_run_multi: cannot create " + nm + ": " + strerror(errno)); return TD_FAIL; }
+			pw.fds.push_back(fd);
+		}
+		pw.file_off.assign(pw.fds.size(), 0);
+	}
+	std::vector<size_t> file_base((size_t)K, 0);      // io.c:917-1001: c
+	{ size_t c = 0; for (int k = 0; k < K; k++) { file_base[(size_t)k] = c; c += (size_t)pw.num_alternatives * (size_t)read_present[(size_t)k]; } }
+	pw.write_pool.reset(new Pool(o.n_threads));
+	const int parse_threads = std::max(1, o.n_threads / K);
+	int rc = TD_OK;
+	for (int k = 0; k < K && rc == TD_OK; k++) {
+		Pipeline& p = *pf[(size_t)k];
+		p.o = o; p.dry = files[k].ctx == nullptr;       // (a file that is not decoded needs no page-locked buffers)
+		p.ready.reset(new Queue<Batch*>((size_t)n_batches));
+		p.done.reset(new Queue<Batch*>((size_t)n_batches));
+		p.free_list.reset(new Queue<Batch*>((size_t)n_batches));
+		std::string err;
+		if (!p.src.open(files[k].path, o.block_bytes, err)) { td_io_set_error(err); rc = TD_FAIL; break; }
+		p.parse_pool.reset(new Pool(parse_threads));
+		for (int b = 0; b < 2; b++) {
+			Batch* q = p.new_batch();
+			if (!q) { rc = TD_FAIL; td_io_set_error("td_stream_run_multi: page-locked memory exhausted"); break; }
+			p.free_list->push(q);
+		}
+	}
+	if (rc != TD_OK) {
+		for (int g : pw.fds) close(g);
+		for (auto& q : pf) release_batches(*q, false);
+		return TD_FAIL;
+	}
+	std::vector<std::thread> th_alloc, th_prod;
+	for (int k = 0; k < K; k++) {
+		Pipeline* p = pf[(size_t)k].get();
+		th_alloc.emplace_back([p, n_batches] { p->allocator(n_batches - 2); });
+		th_prod.emplace_back([p] { p->producer(); });
+	}
+	Queue<Tuple*> done_t((size_t)n_batches);
+	int64_t cnt[TD_NUM_COUNTERS];
+	for (int q = 0; q < TD_NUM_COUNTERS; q++) cnt[q] = 0;
+	// ---- writer: run_rna_dust for the files that are not decoded, the per-record combination, print_all ----
+	std::thread t_write([&] {
+		Tuple* t = nullptr;
+		std::vector<OutBufs> bufs;
+		std::vector<int32_t> ctype, cbar;
+		while (done_t.pop(t)) {
+			const double t0 = now_s();
+			const int64_t n = t->b[0]->n;
+			for (int k = 0; k < K; k++) {
+				Batch* b = t->b[(size_t)k];
+				if (files[k].ctx) { b->seq_src = nullptr; continue; }
+				b->seq_src = b->codes;
+				const int64_t chunk = 16384, nch = (n + chunk - 1) / chunk;
+				pw.write_pool->run(nch, [&](int64_t c) {   // do_rna_dust, barcode_hmm.c:2370-2395 (no -ref filter here)
+					for (int64_t i = c * chunk; i < std::min(n, (c + 1) * chunk); i++) {
+						td_read_result& r = b->res[i];
+						memset(&r, 0, sizeof r);
+						r.mapq = -1.0f; r.barcode = -1; r.fingerprint = -1;        // read_fasta_fastq's defaults, io.c:1698-1702
+						r.read_type = TD_EXTRACT_SUCCESS;
+						if (dust && rna_dust_low(b->codes + b->offs[i], b->offs[i + 1] - b->offs[i], dust)) r.read_type = TD_EXTRACT_FAIL_LOW_COMPLEXITY;
+					}
+				});
+			}
+			ctype.resize((size_t)n); cbar.resize((size_t)n);
+			for (int64_t i = 0; i < n; i++) {          // barcode_hmm.c:329-351
+				int32_t c = -100000;
+				for (int k = 0; k < K; k++) c = std::max(c, t->b[(size_t)k]->res[i].read_type);
+				ctype[(size_t)i] = c;
+				cbar[(size_t)i] = t->b[(size_t)(bar_file >= 0 ? bar_file : 0)]->res[i].barcode;
+				cnt[c & (TD_NUM_OUTCOME_SLOTS - 1)]++;                                      // the controller's counting, :354-384
+				if (c == TD_EXTRACT_SUCCESS && cbar[(size_t)i] >= 0) cnt[TD_NUM_OUTCOME_SLOTS + (cbar[(size_t)i] & 0xFF)]++;
+			}
+			bool ok = true;
+			for (int k = 0; k < K && ok; k++)
+				if (read_present[(size_t)k] > 0) ok = pw.write_batch(t->b[(size_t)k], bufs, ctype.data(), cbar.data(), file_base[(size_t)k]);
+			pw.st.n_reads += n; pw.st.n_batches++;
+			pw.st.write_s += now_s() - t0;
+			for (int k = 0; k < K; k++) { t->b[(size_t)k]->pieces.clear(); t->b[(size_t)k]->seq_src = nullptr; (void)pf[(size_t)k]->free_list->push(t->b[(size_t)k]); }
+			delete t;
+			if (!ok) return;
+		}
+	});
+	// ---- the calling thread: one record range of every file at a time, `depth` of them on the devices ----
+	std::deque<Tuple*> flying;
+	auto retire = [&]() -> bool {
+		Tuple* t = flying.front();
+		flying.pop_front();
+		const double t0 = now_s();
+		bool ok = true;
+		for (int k = 0; k < K; k++)
+			for (int d = 0; d < N; d++)
+				if (files[k].ctx && t->tickets[(size_t)k][(size_t)d] && td_wait(files[k].ctx[d], t->tickets[(size_t)k][(size_t)d]) != TD_OK) {
+					if (ok) fail_all(std::string("td_stream_run_multi: ") + td_last_error(files[k].ctx[d]));
+					ok = false;
+				}
+		pw.st.decode_s += now_s() - t0;
+		if (!ok) { delete t; return false; }
+		return done_t.push(t);
+	};
+	bool first = true;
+	int name_format = -1;
+	while (!pw.failed()) {
+		Tuple* t = new Tuple();
+		t->b.assign((size_t)K, nullptr);
+		t->tickets.assign((size_t)K, std::vector<int64_t>((size_t)N, 0));
+		int n_closed = 0;
+		bool bad = false;
+		for (int k = 0; k < K && !bad; k++) {
+			for (;;) {   // (nothing ready from this file and record ranges in flight: retire the oldest -- its buffers may be what the reader waits for)
+				Batch* b = nullptr;
+				const int got = flying.empty() ? (pf[(size_t)k]->ready->pop(b) ? 1 : -1) : pf[(size_t)k]->ready->try_pop(b);
+				if (got == 1) { t->b[(size_t)k] = b; break; }
+				if (got < 0) { n_closed++; break; }
+				if (!retire()) { bad = true; break; }
+			}
+		}
+		if (bad || n_closed == K) { for (Batch* b : t->b) if (b) (void)b; delete t; break; }
+		bool same_n = n_closed == 0;
+		for (int k = 1; k < K && same_n; k++) same_n = t->b[(size_t)k]->n == t->b[0]->n;
+		if (!same_n) {   // barcode_hmm.c:257-268
+			fail_all("td_stream_run_multi: the input files differ in their number of records");
+			delete t;
+			break;
+		}
+		const int64_t n = t->b[0]->n;
+		if (first) {     // the first 1000 names of every pair of files name the same reads (barcode_hmm.c:272-289)
+			first = false;
+			bool differ = false;
+			std::string na, nb;
+			for (int64_t i = 0; i < std::min<int64_t>(1000, n) && !differ; i++) {
+				na = record_name(*t->b[0], i);
+				for (int k = 1; k < K && !differ; k++) { nb = record_name(*t->b[(size_t)k], i); differ = names_differ(na, nb, name_format); }
+			}
+			if (differ) { fail_all("td_stream_run_multi: the input files seem to contain reads in different order: " + na + " / " + nb); delete t; break; }
+		}
+		if ((int)flying.size() >= depth && !retire()) { delete t; break; }
+		const double t0 = now_s();
+		bool ok = true;
+		for (int k = 0; k < K && ok; k++) {
+			if (!files[k].ctx) continue;
+			Batch* b = t->b[(size_t)k];
+			for (int d = 0; d < N && ok; d++) {      // run_pHMM's contiguous ranges over the devices (barcode_hmm.c:1911-1922)
+				const int64_t interval = n / N, lo = (int64_t)d * interval, hi = (d == N - 1) ? n : lo + interval;
+				if (hi <= lo) continue;
+				if (td_submit(files[k].ctx[d], b->codes, 0, b->offs + lo, hi - lo, TD_MODE_GET_LABEL, b->res + lo, nullptr, b->seq_out + b->offs[lo],
+				              &t->tickets[(size_t)k][(size_t)d]) != TD_OK) {
+					fail_all(std::string("td_stream_run_multi: ") + td_last_error(files[k].ctx[d]));
+					ok = false;
+				}
+			}
+		}
+		pw.st.decode_s += now_s() - t0;
+		flying.push_back(t);
+		if (!ok) break;
+	}
+	while (!flying.empty() && !pw.failed()) if (!retire()) break;
+	if (pw.failed()) {   // nothing of ours may stay queued on the devices
+		for (Tuple* t : flying) {
+			for (int k = 0; k < K; k++) for (int d = 0; d < N; d++) if (files[k].ctx && t->tickets[(size_t)k][(size_t)d]) (void)td_wait(files[k].ctx[d], t->tickets[(size_t)k][(size_t)d]);
+			delete t;
+		}
+		flying.clear();
+		done_t.abort();
+	}
+	done_t.close();
+	t_write.join();
+	for (int k = 0; k < K; k++) {
+		Pipeline& p = *pf[(size_t)k];
+		if (pw.failed()) p.fail(pw.err);
+		th_prod[(size_t)k].join();
+		{ std::lock_guard<std::mutex> lk(p.all_mu); p.stop_alloc = true; }
+		p.hint_cv.notify_all();
+		p.free_list->abort();
+		th_alloc[(size_t)k].join();
+		pw.st.bytes_in += p.st.bytes_in; pw.st.parse_s += p.st.parse_s; pw.st.read_s += p.st.read_s;
+		if (p.failed() && !pw.failed()) pw.fail(p.err);
+	}
+	for (int fd : pw.fds) if (close(fd) != 0 && !pw.failed()) pw.fail(std::string("td_stream_run_multi: close failed: ") + strerror(errno));
+	for (auto& q : pf) release_batches(*q, !pw.failed());
+	pw.st.wall_s = now_s() - t_start;
+	if (stats) *stats = pw.st;
+	if (counts) for (int q = 0; q < TD_NUM_COUNTERS; q++) counts[q] = cnt[q];
+	if (pw.failed()) { td_io_set_error(pw.err); return TD_FAIL; }
+	return TD_OK;
 }

@@ -25,9 +25,9 @@ ABI_SYMBOLS = [
 ]
 MULTI_ABI_SYMBOLS = ["td_shard_bounds", "td_count_outcomes", "td_multi_create", "td_multi_destroy", "td_multi_last_error",
                      "td_multi_size", "td_multi_ctx", "td_multi_model_upload", "td_multi_set_params", "td_multi_set_window", "td_multi_set_artifacts",
-                     "td_multi_decode", "td_multi_counts", "td_multi_counts_reset", "td_multi_uses_rccl", "td_bind_host_to_device"]
+                     "td_multi_decode", "td_multi_counts", "td_multi_counts_reset", "td_multi_uses_rccl", "td_bind_host_to_device", "td_host_halves_bench"]
 IO_ABI_SYMBOLS = ["td_io_last_error", "td_reads_parse", "td_reads_free", "td_writer_open", "td_writer_write", "td_writer_close",
-                  "td_fasta_parse", "td_fasta_free", "td_stream_run", "td_stream_release", "td_format_q"]
+                  "td_fasta_parse", "td_fasta_free", "td_stream_run", "td_stream_run_multi", "td_stream_release", "td_format_q"]
 MODEL_ABI_SYMBOLS = ["td_arch_parse", "td_arch_free", "td_sequence_stats", "td_sequence_stats_window", "td_model_build", "td_model_tables_free",
                      "td_calibration_emit", "td_calibration_select", "td_calibration_free", "td_estimate_threshold",
                      "td_compare_architectures", "td_simreads", "td_text_free"]
@@ -448,6 +448,48 @@ def stream_run(ctx, in_path, segments=None, out_prefix=None, batch_reads=0, n_th
     finally:
         if arch:
             lib.td_arch_free(arch)
+
+
+class _StreamFile(C.Structure):
+    _fields_ = [("path", C.c_char_p), ("arch", C.c_void_p), ("ctx", C.POINTER(C.c_void_p))]
+
+
+def stream_run_multi(files, out_prefix, n_devices=1, dust=100, batch_reads=0, n_threads=0, block_bytes=0):
+    """td_stream_run_multi: the input files of one paired / multi-read run in lock-step.  files: a list of
+    (path, segments, contexts) -- contexts = one TagdustHip per device holding that file's model and parameters, or None for a
+    file whose architecture is a single read segment (not decoded: run_rna_dust).  Returns (statistics dict, counters int64[264])."""
+    lib = load_library()
+    lib.td_stream_run_multi.argtypes = [C.POINTER(_StreamFile), C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(_StreamOpts),
+                                        C.POINTER(_StreamStats), C.c_void_p]
+    lib.td_io_last_error.restype = C.c_char_p
+    arr = (_StreamFile * len(files))()
+    archs, keep = [], []
+    try:
+        for k, (path, segments, ctxs) in enumerate(files):
+            a = C.c_void_p()
+            sa = (C.c_char_p * len(segments))(*[s.encode() for s in segments])
+            if lib.td_arch_parse(sa, len(segments), C.byref(a)) != 0:
+                raise TdError("td_arch_parse failed for %r" % (segments,))
+            archs.append(a)
+            arr[k].path = os.fsencode(path)
+            arr[k].arch = a
+            if ctxs is not None:
+                if len(ctxs) != n_devices:
+                    raise TdError("stream_run_multi: %d contexts for %d devices" % (len(ctxs), n_devices))
+                cp = (C.c_void_p * n_devices)(*[c.h for c in ctxs])
+                keep.append(cp)
+                arr[k].ctx = C.cast(cp, C.POINTER(C.c_void_p))
+        o = _StreamOpts(int(batch_reads), int(n_threads), int(block_bytes))
+        st = _StreamStats()
+        counts = np.zeros(264, np.int64)
+        rc = lib.td_stream_run_multi(arr, len(files), int(n_devices), os.fsencode(out_prefix), int(dust), C.byref(o), C.byref(st), counts.ctypes.data)
+        if rc != 0:
+            raise TdError(lib.td_io_last_error().decode() or "td_stream_run_multi failed")
+        return {k: getattr(st, k) for k, _ in _StreamStats._fields_}, counts
+    finally:
+        for a in archs:
+            if a:
+                lib.td_arch_free(a)
 
 
 def stream_release():

@@ -287,6 +287,46 @@ def test_page_locked_input_may_be_reused_after_submit():
         pin.free()
 
 
+def test_stable_page_locked_input_keeps_the_compact_egress():
+    """Option "stable_input": the caller leaves its page-locked input alone until td_wait -- td_submit then neither waits for the
+    upload nor falls back to full device-side copies of the rewritten sequences (the keep bits are applied to the caller's own
+    buffer).  Same bytes as the synchronous path, for base codes and for sequence text, labels included; and without the promise
+    (default) a refilled buffer still gives the right bytes (test above)."""
+    from tagdust_amd import RESULT_DTYPE
+    from tagdust_amd.lib import PinnedArray
+    import bench
+    bench.select_workload("c3")
+    g = bench.load_model()
+    n, L = 1 << 17, bench.READ_LEN
+    offs = np.arange(n + 1, dtype=np.int64) * L
+    c = _ctx(g, 1, depth=3)
+    ref = _ctx(g, 1, depth=1)
+    pins = [PinnedArray((n * L,), np.uint8) for _ in range(3)]
+    try:
+        c.set_option("stable_input", 1)
+        assert c.get_option("stable_input") == 1
+        for ascii_ in (False, True):
+            batches = [bench.synth_batch(n, 777 + k).reshape(-1) for k in range(3)]
+            outs, tickets = [], []
+            for b, pin in zip(batches, pins):
+                pin.array[:] = np.frombuffer(b"ACGTN", np.uint8)[b] if ascii_ else b
+                res = np.zeros(n, RESULT_DTYPE); sq = np.full(n * L, 99, np.uint8); lab = np.full(n * (L + 1), 99, np.int8)
+                outs.append((res, sq, lab))
+                tickets.append(c.submit(pin.array, offs, res=res, seq_out=sq, labels=lab, ascii=ascii_))
+            for t in tickets:
+                c.wait(t)
+            for b, (res, sq, lab) in zip(batches, outs):
+                ref.upload_batch(b, offs)
+                ref.run()
+                r2, l2, s2 = ref.download()
+                assert res.tobytes() == r2.tobytes() and np.array_equal(sq, s2) and np.array_equal(lab, l2)
+    finally:
+        c.close()
+        ref.close()
+        for p_ in pins:
+            p_.free()
+
+
 def test_length_outliers_get_their_own_wave_slots(monkeypatch):
     """A batch of 150-base reads with 0.1 % reads of 1000 bases: the workspace keeps the geometry of the many (the long tiles get
     wave slots of their own), both pipeline streams stay in use, and every output byte equals what one geometry for all gives

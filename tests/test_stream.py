@@ -313,3 +313,59 @@ def test_stream_at_full_batch_size(tmp_path):
     assert set(got) == set(want)
     for k in want:
         assert got[k] == want[k], "output file *%s differs" % k
+
+
+def _thr_lines(path):
+    out = {}
+    for l in open(path).read().splitlines():
+        f = l.split("\t")
+        if len(f) >= 3 and f[1].strip().replace(".", "").replace("%", "").isdigit():
+            out[f[2].strip()] = f[1].strip()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,n_ctx", [(1 << 20, 1), (70001, 2)], ids=["2^20-records", "two-contexts"])
+def test_multi_file_stream_equals_the_reference_binary(tmp_path, n, n_ctx):
+    """BASELINE configs[3] at the library level: the CASAVA three-read shape -- the reference's own index reads (fixture
+    casava_index) tiled to n records with the two 76-nt read files synthesised around them -- through td_stream_run_multi: three
+    readers in lock-step, the index file decoded (over n_ctx contexts: run_pHMM's contiguous ranges), reads 1 and 3 through
+    run_rna_dust, outcomes combined per record (barcode_hmm.c:329-351), print_all's READ1 / READ2 files.  Everything from the
+    library alone (statistics over the reference's first batch, model, threshold calibration, decode, files) == the files and the
+    counts of the unmodified reference binary on the same three files."""
+    if not os.path.exists(os.path.join(RBIN, "tagdust_rtest")):
+        pytest.skip("oracle/_ref binaries not built")
+    import bench
+    from tagdust_amd import TagdustHip
+    from tagdust_amd import lib as tdlib
+    d = str(tmp_path)
+    r1, r2, r3, segs = bench.write_casava_files(d, n)
+    g = load_golden("casava_index")
+    args = str(g["cmdline"]).split()
+    subprocess.run([os.path.join(RBIN, "tagdust_rtest")] + args + ["-t", "16", r2, r1, r3, "-o", os.path.join(d, "cpu")], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    # the reference takes its sequence statistics from the first batch it reads: 1000 records in the -DRTEST build (barcode_hmm.c:159-166)
+    head = b"".join(open(r2, "rb").readlines()[:4000])
+    pr = tdlib.ParsedReads(head, 1)
+    ctxs = [TagdustHip(0) for _ in range(n_ctx)]
+    try:
+        thr = tdlib.estimate_threshold(ctxs[0], segs, pr.codes, pr.offs, float(g["d"]), seed=42, n_reads=4000, rng=1)
+        model, _ = tdlib.build_model(segs, pr.codes, pr.offs, 0.05, float(g["d"]))
+        for c in ctxs:
+            c.set_option("poison_workspace", 1)
+            c.upload_model(model)
+            c.set_params(thr, 16, 100)
+        st, cnt = tdlib.stream_run_multi([(r2, segs, ctxs), (r1, ["R:N"], None), (r3, ["R:N"], None)], os.path.join(d, "gpu"),
+                                         n_devices=n_ctx, dust=100, batch_reads=1 << 18 if n_ctx == 1 else 9999, n_threads=4)
+    finally:
+        pr.close()
+        for c in ctxs:
+            c.close()
+    assert st["n_reads"] == n
+    a, b = _files(d, "cpu"), _files(d, "gpu")
+    assert len(a) == 26 and set(a) == set(b), (sorted(a), sorted(b))
+    for k in a:
+        assert a[k] == b[k], "output file *%s differs" % k
+    log = _thr_lines(os.path.join(d, "cpu_logfile.txt"))
+    assert int(log["successfully extracted"]) == cnt[0] and int(log["problems with architecture"]) == cnt[1]
+    assert int(log["low complexity"]) == cnt[6] and int(log["total input reads"]) == n == int(cnt[:8].sum())

@@ -25,6 +25,7 @@ def worker(tag, iters, seed, errors):
     rng = np.random.default_rng(seed)
     fixtures = [load_golden(n) for n in ("c2_b4_r", "c3_b6_s_r_p", "umi_f_s_r", "scen2_endloss", "c5_b96_f_r_p")]
     c = TagdustHip(0)
+    c.set_option("poison_workspace", 1)    # workspace, label-run and keep-bit tables filled with 0xFF before every launch / download
     ref = {}
     try:
         for it in range(iters):

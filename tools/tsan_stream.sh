@@ -2,7 +2,8 @@
 # The streaming pipeline (csrc/td_stream.cpp: reader/parser thread, writer thread, two thread pools, the caller's thread) under
 # ThreadSanitizer on the CPU: td_stream.cpp + td_fastq.cpp as they are, the device entry points replaced by stand-ins
 # (tools/tsan_stream/stub.cpp), a 60 000-read ragged FASTQ file in batches of 777 reads and blocks of 20 KB -- parse-only and
-# with the stubbed decode + real formatting / appends, each twice (the second run reuses the cached batch buffers).
+# with the stubbed decode + real formatting / appends, each twice (the second run reuses the cached batch buffers), and the
+# multi-file pipeline (td_stream_run_multi: two input files in lock-step, two "devices", one file not decoded).
 # usage: tools/tsan_stream.sh      (prints the four result lines; any ThreadSanitizer report goes to stderr)
 set -e
 cd "$(dirname "$0")/.."
@@ -17,4 +18,4 @@ with open('/tmp/td_tsan/in.fq', 'wb') as f:
         L = int(rng.randint(20, 120)); s = ''.join(rng.choice(list('ACGTN'), L)); f.write(('@r%d x\n%s\n+\n%s\n' % (i, s, 'I' * L)).encode())
 PY
 cd $OUT
-for mode in "" decode; do ./tsan_stream in.fq 777 4 20000 $mode; done
+for mode in "" decode multi; do ./tsan_stream in.fq 777 4 20000 $mode; done
