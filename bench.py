@@ -804,7 +804,7 @@ def main():
     if rank == 0 and args.extras and world == 1:
         # beside the headline: the same pipeline with page-locked caller buffers, and BASELINE configs[1] / configs[4]
         # (parity-test cases per the contract, timed here so that their rates are on the driver's record)
-        for key, wl, nn, st, pin in (("c3_pinned_io", args.workload, n, 12, True), ("config2", "c2", n, 16, False),
+        for key, wl, nn, st, pin in (("c3_pinned_io", args.workload, n, args.steps, True), ("config2", "c2", n, 16, False),
                                      ("config5", "c5", n // 4, 8, False)):
             try:
                 c2, m2, go2, st2, ko2, close2, _ = measure_workload(wl, nn, st, 3, dev_index, args.specialize, args.depth, pin,

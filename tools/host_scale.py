@@ -49,11 +49,15 @@ def main():
         quota = None
     rec = {"what": "host halves of td_submit / td_wait (td_host_halves_bench), no device; config-3 batch shape",
            "reads_per_batch": n, "read_len": L, "cpus_in_affinity_mask": len(avail), "cgroup_cpu_quota": quota,
+           "note": "threads per process = min(8, CPUs the job may use / processes): with a cgroup quota the N processes SHARE that quota -- the figures then say what that many CPUs sustain, not what an N-GPU node with N such allotments does",
            "host": os.uname().nodename, "collected": time.strftime("%Y-%m-%dT%H:%MZ", time.gmtime()), "runs": []}
     for mode, mname in ((0, "pageable caller buffers (staging copy in, records copied out)"), (1, "page-locked caller buffers, stable_input (no staging copies)")):
         for procs in (1, 2, 4, 8):
             share = max(1, len(avail) // procs)
-            threads = min(8, share)
+            # threads: what bench.py gives a rank's copy pool (its share of the CPUs, at most 8) -- of the CPUs this job may really
+            # use: a cgroup quota below the affinity mask's width (the pool's 1-GPU boxes: 16 of 256) is what N ranks share here
+            budget = int(quota) if quota else len(avail)
+            threads = max(1, min(8, share, budget // procs))
             iters = 12
             ps = []
             t0 = time.time()
