@@ -854,7 +854,7 @@ static int ensure_workspace(td_ctx* c, TdSlot& s)
 		if (s.lmax > c->prune_lcap || !c->d_prune) {
 			// bound tables of the position pruning, for reads up to lcap bases (kernels in flight read the old ones)
 			HIPCHK(c, sync_compute(c));
-			const int lcap = (s.lmax + 2 + 255) / 256 * 256, stride = lcap + 8;
+			const int lcap = (s.lmax + 2 + 255) / 256 * 256, stride = lcap + 24;   // (the scans request TDS_SCAN_B = 16 entries at a time: spare entries behind lcap)
 			std::vector<float> tab;
 			const int ps = td_spec_prune_segs(&c->m_desc), sf = td_spec_prune_sfx(&c->m_desc);
 			// (the bound recurrences cost columns x positions on the host: for reads beyond 8192 bases the tables stay zero, which
