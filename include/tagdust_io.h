@@ -68,7 +68,11 @@ int  td_writer_close(td_writer* w);
  * file is mapped, not read.  Batches hold exactly batch_reads records, whatever the block size.
  * The output files are those td_writer_open names, byte for byte what td_reads_parse / td_writer_write give for the whole
  * text at once.  ctx == NULL: a parse-only run (no GPU, nothing written) that fills stats, codes_fnv included.
- * Errors: a decompressor that ends with a non-zero status (truncated / corrupt .gz, .bz2) fails the run -- the reference
+ * Alignment files (.sam, .bam, .sam.gz, .bam.gz) come as text from `samtools view -SF 768 <file>` / `samtools view -F 768 <file>`
+ * (a .gz through zcat first) exactly as io_handler() starts it (io.c:467-575), and a record is QNAME, SEQ and QUAL of a line
+ * that does not start with '@' (read_sam_chunk, io.c:1498-1660); samtools must be on PATH, as for the reference.  A line with
+ * fewer than 11 fields or without one quality per base fails the run (the reference reads past the field it did not find).
+ * Errors: a decompressor or samtools that ends with a non-zero status (truncated / corrupt .gz, .bz2; no samtools) fails the run -- the reference
  * ignores pclose()'s status and writes a partial file set.  A mapped plain file must not shrink while the call runs (the parse
  * threads read the mapping; the kernel answers a truncated mapping with SIGBUS, as for any mmap reader).  When page-locked
  * memory runs short the pipeline runs with the batches it could get (at least one), more slowly, and fails with "page-locked

@@ -180,13 +180,26 @@ public:
 		auto ends = [&](const char* sfx) { const size_t n = strlen(sfx); return p.size() >= n && p.compare(p.size() - n, n, sfx) == 0; };
 		struct stat st;
 		if (p != "-" && stat(path, &st) != 0) { err = "td_stream_run: cannot find input file " + p; return false; }
-		if (ends(".sam") || ends(".bam") || ends(".sam.gz") || ends(".bam.gz")) { err = "td_stream_run: SAM/BAM input is not supported (FASTQ/FASTA only): " + p; return false; }
+		std::string q;
+		for (char ch : p) { if (ch == '\'') q += "'\\''"; else q += ch; }
+		const bool sam = ends(".sam") || ends(".sam.gz"), bam = ends(".bam") || ends(".bam.gz");
+		if (sam || bam) {
+			// io_handler(), io.c:467-575: alignments come as text from `samtools view` (-S for SAM text), secondary and
+			// QC-failed records dropped (-F 768); a .gz of either goes through zcat first.  read_sam_chunk (io.c:1498-1660) takes
+			// QNAME, SEQ and QUAL of every line that does not start with '@'.
+			const std::string view = std::string("samtools view ") + (sam ? "-SF 768 " : "-F 768 ");
+			cmd_ = ends(".gz") ? "zcat -- '" + q + "' | " + view + "-" : view + "'" + q + "'";
+			if (p == "-") { err = "td_stream_run: SAM/BAM input from stdin is not supported"; return false; }
+			pipe_ = popen(cmd_.c_str(), "r");
+			if (!pipe_) { err = "td_stream_run: cannot start " + cmd_; return false; }
+			fd_in_ = fileno(pipe_);
+			sam_ = true;
+			return true;
+		}
 		if (ends(".gz") || ends(".bz2")) {             // io_handler(), io.c:382-608: zcat / bzcat through popen
-			std::string q;
-			for (char ch : p) { if (ch == '\'') q += "'\\''"; else q += ch; }
-			const std::string cmd = std::string(ends(".gz") ? "zcat" : "bzcat") + " -- '" + q + "'";
-			pipe_ = popen(cmd.c_str(), "r");
-			if (!pipe_) { err = "td_stream_run: cannot start " + cmd; return false; }
+			cmd_ = std::string(ends(".gz") ? "zcat" : "bzcat") + " -- '" + q + "'";
+			pipe_ = popen(cmd_.c_str(), "r");
+			if (!pipe_) { err = "td_stream_run: cannot start " + cmd_; return false; }
 			fd_in_ = fileno(pipe_);
 			return true;
 		}
@@ -242,9 +255,17 @@ public:
 			// not the end of the input (io_handler's pclose, io.c:382-608, ignores it; a partial set of output files helps nobody)
 			const int status = pclose(pipe_);
 			pipe_ = nullptr;
-			if (status != 0) { err = "td_stream_run: the decompressor of the input file failed (status " + std::to_string(status) + "): truncated or corrupt input"; return nullptr; }
+			if (status != 0) {
+				err = "td_stream_run: `" + cmd_ + "` failed (status " + std::to_string(status) + "): truncated or corrupt input" + (sam_ ? ", or no samtools on PATH" : "");
+				return nullptr;
+			}
 		}
 		*read_s += now_s() - t0;
+		if (sam_) {
+			std::shared_ptr<Block> r = sam_block(b, have, end_of_input, err);
+			if (r && r->len == 0) return eof_ ? nullptr : next(read_s, err);   // header lines only
+			return r;
+		}
 		if (first_block_) { fasta_ = have > 0 && b->owned[0] == '>'; first_block_ = false; }
 		int64_t cut = have;
 		if (!end_of_input) {
@@ -268,7 +289,54 @@ public:
 	}
 
 private:
+	// Alignment text -> the four-line records the parser takes: '@' QNAME, SEQ, '+', QUAL (fields 1, 10 and 11 of every line that
+	// is not a header line, read_sam_chunk, io.c:1498-1660).  Whole lines only; the rest is carried over to the next block.
+	std::shared_ptr<Block> sam_block(std::shared_ptr<Block> b, int64_t have, const bool end_of_input, std::string& err)
+	{
+		int64_t cut = have;
+		if (!end_of_input) {
+			while (cut > 0 && b->owned[cut - 1] != '\n') --cut;
+			if (cut == 0) { err = "td_stream_run: no line end within a block of SAM input (raise block_bytes)"; return nullptr; }
+			carry_.assign(b->owned + cut, b->owned + have);
+		} else {
+			eof_ = true;
+		}
+		auto out = std::make_shared<Block>();
+		out->owned = (char*)malloc((size_t)cut + 8);      // a record shrinks: 11+ tab-separated fields against 3 of them and 5 bytes
+		if (!out->owned) { err = "td_stream_run: out of memory"; return nullptr; }
+		char* o = out->owned;
+		const char* t = b->owned;
+		const char* const end = t + cut;
+		auto blank = [](const char ch) { return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\v' || ch == '\f'; };
+		while (t < end) {
+			const char* nl = (const char*)memchr(t, '\n', (size_t)(end - t));
+			const char* le = nl ? nl : end;
+			if (le > t && t[0] != '@') {
+				const char* f[12];
+				int nf = 0;
+				const char* c = t;
+				f[nf++] = c;
+				while (c < le && nf < 12) { if (blank(*c)) f[nf++] = c + 1; ++c; }
+				if (nf < 11) { err = "td_stream_run: SAM line with fewer than 11 fields: " + std::string(t, (size_t)std::min<int64_t>(le - t, 60)); return nullptr; }
+				auto field_end = [&](const char* s) { while (s < le && !blank(*s)) ++s; return s; };
+				const char* n1 = field_end(f[0]);
+				const char* s1 = field_end(f[9]);
+				const char* q1 = field_end(f[10]);
+				if (q1 - f[10] != s1 - f[9]) { err = "td_stream_run: SAM record without one quality per base: " + std::string(f[0], (size_t)(n1 - f[0])); return nullptr; }
+				*o++ = '@'; memcpy(o, f[0], (size_t)(n1 - f[0])); o += n1 - f[0]; *o++ = '\n';
+				memcpy(o, f[9], (size_t)(s1 - f[9])); o += s1 - f[9]; *o++ = '\n';
+				*o++ = '+'; *o++ = '\n';
+				memcpy(o, f[10], (size_t)(q1 - f[10])); o += q1 - f[10]; *o++ = '\n';
+			}
+			t = nl ? nl + 1 : end;
+		}
+		out->data = out->owned; out->len = o - out->owned;
+		return out;
+	}
+
 	int fd_ = -1, fd_in_ = -1;
+	std::string cmd_;
+	bool sam_ = false;
 	FILE* pipe_ = nullptr;
 	void* map_ = nullptr;
 	int64_t map_len_ = 0, map_pos_ = 0, block_ = 0;

@@ -369,3 +369,167 @@ def test_multi_file_stream_equals_the_reference_binary(tmp_path, n, n_ctx):
     log = _thr_lines(os.path.join(d, "cpu_logfile.txt"))
     assert int(log["successfully extracted"]) == cnt[0] and int(log["problems with architecture"]) == cnt[1]
     assert int(log["low complexity"]) == cnt[6] and int(log["total input reads"]) == n == int(cnt[:8].sum())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SAM / BAM input: io_handler() pipes the file through `samtools view` (io.c:467-575) and read_sam_chunk() takes QNAME, SEQ and
+# QUAL of every line (io.c:1498-1660).  The image has no samtools; a stand-in on PATH that does what `view [-S] -F <mask> <file|->`
+# does with alignment TEXT (drop header lines and records with a masked flag bit) serves both td_stream_run and the reference
+# binary, which start it the same way.
+_SAMTOOLS = '''#!/usr/bin/env python3
+import sys
+a = sys.argv[1:]
+assert a[0] == "view", a
+mask, path = 0, None
+i = 1
+while i < len(a):
+    if a[i] in ("-SF", "-F"):
+        mask = int(a[i + 1]); i += 2
+    else:
+        path = a[i]; i += 1
+src = sys.stdin.buffer if path == "-" else open(path, "rb")
+out = sys.stdout.buffer
+for line in src:
+    if line.startswith(b"@"):
+        continue
+    f = line.split(b"\\t")
+    if int(f[1]) & mask:
+        continue
+    out.write(line)
+'''
+
+
+def _sam_env(tmp_path, monkeypatch):
+    d = tmp_path / "bin"
+    d.mkdir()
+    p = d / "samtools"
+    p.write_text(_SAMTOOLS)
+    p.chmod(0o755)
+    monkeypatch.setenv("PATH", str(d) + os.pathsep + os.environ["PATH"])
+    return str(d)
+
+
+def _sam_text(names, seqs, quals, seed=0, drop_every=0):
+    """Alignment text for the given reads: a header, every record with 11 mandatory fields and some optional ones; with
+    drop_every, an extra secondary (256) or QC-failed (512) record in front of every drop_every-th read -- `view -F 768` drops them."""
+    rng = np.random.RandomState(seed)
+    out = ["@HD\tVN:1.6\tSO:unsorted\n", "@SQ\tSN:chr1\tLN:1000000\n", "@PG\tID:x\tCL:a b c\n"]
+    for i, (n, s, q) in enumerate(zip(names, seqs, quals)):
+        if drop_every and i % drop_every == 0:
+            out.append("%s\t%d\tchr1\t%d\t0\t%dM\t*\t0\t0\t%s\t%s\n" % (n + "_x", 256 if i % 2 else 512, 5 + i, len(s), s[::-1], q))
+        flag = int(rng.choice([0, 4, 16]))
+        opt = "\tNM:i:%d\tXX:Z:some text" % (i % 3) if i % 4 else ""
+        out.append("%s\t%d\t%s\t%d\t%d\t%dM\t*\t0\t0\t%s\t%s%s\n" % (n, flag, "*" if flag == 4 else "chr1", 1 + i, int(rng.randint(0, 60)), len(s), s, q, opt))
+    return "".join(out).encode()
+
+
+def _plain_reads(n, seed):
+    rng = np.random.RandomState(seed)
+    names, seqs, quals = [], [], []
+    for i in range(n):
+        L = int(rng.randint(1, 120))
+        names.append("read%d/1" % i)
+        seqs.append("".join(rng.choice(list("ACGTNacgt"), L, p=[.23, .23, .23, .23, .04, .01, .01, .01, .01])))
+        quals.append("".join(chr(c) for c in rng.randint(33, 74, L)))
+    return names, seqs, quals
+
+
+@pytest.mark.parametrize("kind", ["sam", "bam", "sam.gz"])
+def test_sam_input_goes_through_samtools_view(tmp_path, monkeypatch, kind):
+    """Parse stage alone (no GPU): the records of alignment text are those of the FASTQ text with the same names, bases and
+    qualities; header lines, secondary and QC-failed records do not count; blocks cut lines anywhere."""
+    from tagdust_amd import lib as tdlib
+    _sam_env(tmp_path, monkeypatch)
+    names, seqs, quals = _plain_reads(3000, 21)
+    fq = "".join("@%s\n%s\n+\n%s\n" % t for t in zip(names, seqs, quals)).encode()
+    pr = tdlib.ParsedReads(fq, 1)
+    want = (pr.n, _fnv(pr.codes, pr.offs))
+    pr.close()
+    sam = _sam_text(names, seqs, quals, 3, drop_every=17)
+    path = str(tmp_path / ("in." + kind))
+    if kind.endswith(".gz"):
+        with gzip.open(path, "wb") as fh:
+            fh.write(sam)
+    else:
+        open(path, "wb").write(sam)      # (a .bam here is alignment text as well: the stand-in does not decode BGZF)
+    for block in (4096, 1 << 20):
+        st = tdlib.stream_run(None, path, batch_reads=700, n_threads=2, block_bytes=block)
+        assert (st["n_reads"], st["codes_fnv"]) == want and st["n_batches"] == 5
+
+
+def test_sam_input_without_samtools_is_an_error(tmp_path, monkeypatch):
+    """No samtools on PATH: the shell's status comes back through pclose and ends the run with a message that names the
+    command (the reference exits on the empty stream it then reads)."""
+    from tagdust_amd import lib as tdlib
+    names, seqs, quals = _plain_reads(10, 2)
+    path = str(tmp_path / "in.sam")
+    open(path, "wb").write(_sam_text(names, seqs, quals))
+    empty = tmp_path / "nobin"
+    empty.mkdir()
+    for tool in ("sh", "zcat", "cat"):
+        for d in os.environ["PATH"].split(os.pathsep):
+            if os.path.exists(os.path.join(d, tool)):
+                os.symlink(os.path.join(d, tool), str(empty / tool))
+                break
+    monkeypatch.setenv("PATH", str(empty))
+    with pytest.raises(Exception, match="samtools"):
+        tdlib.stream_run(None, path, batch_reads=100, n_threads=1, block_bytes=4096)
+
+
+def test_malformed_sam_lines_are_errors(tmp_path, monkeypatch):
+    from tagdust_amd import lib as tdlib
+    _sam_env(tmp_path, monkeypatch)
+    path = str(tmp_path / "in.sam")
+    open(path, "wb").write(b"r1\t0\tchr1\t1\t0\t4M\t*\t0\t0\tACGT\n")
+    with pytest.raises(Exception, match="fewer than 11 fields"):
+        tdlib.stream_run(None, path, batch_reads=100, n_threads=1, block_bytes=4096)
+    open(path, "wb").write(b"r1\t0\tchr1\t1\t0\t4M\t*\t0\t0\tACGT\t*\n")
+    with pytest.raises(Exception, match="one quality per base"):
+        tdlib.stream_run(None, path, batch_reads=100, n_threads=1, block_bytes=4096)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(RBIN, "tagdust_rtest")), reason="oracle/_ref binaries not built")
+@pytest.mark.parametrize("name", ["c3_b6_s_r_p", "c2_b4_r"])
+def test_sam_stream_equals_the_reference_binary(tmp_path, monkeypatch, name):
+    """The fixture's reads as alignment text (with header lines and records `view -F 768` drops), three times over, through the
+    reference binary and through td_stream_run with the reference's batch size: the same files."""
+    from tagdust_amd import TagdustHip
+    from tagdust_amd import lib as tdlib
+    from test_dropin_gpu import _write_fastq
+    _sam_env(tmp_path, monkeypatch)
+    g = load_golden(name)
+    fq = str(tmp_path / "one.fq")
+    _write_fastq(g, fq)
+    lines = open(fq, "rb").read().decode().split("\n")
+    names = [l[1:].split()[0] for l in lines[0::4] if l]
+    seqs = [l for l in lines[1::4]][:len(names)]
+    quals = [l for l in lines[3::4]][:len(names)]
+    keep = [i for i in range(len(names)) if len(seqs[i]) > 0]
+    names, seqs, quals = [[v[i] for i in keep] * 3 for v in (names, seqs, quals)]
+    names = ["%s_%d" % (n, i) for i, n in enumerate(names)]
+    sam = str(tmp_path / "in.sam")
+    open(sam, "wb").write(_sam_text(names, seqs, quals, 5, drop_every=9))
+    args = str(g["cmdline"]).split()
+    p = subprocess.run([os.path.join(RBIN, "tagdust_rtest")] + args + ["-t", "2", sam, "-o", "cpu"], cwd=str(tmp_path),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-1500:]
+    segs = _segments(g)
+    text = "".join("@%s\n%s\n+\n%s\n" % t for t in zip(names, seqs, quals)).encode()
+    head = tdlib.ParsedReads(text, 1)
+    hc, ho = head.codes.copy(), head.offs.copy()
+    head.close()
+    c = TagdustHip(0)
+    try:
+        thr = tdlib.estimate_threshold(c, segs, hc, ho, float(g["d"]), seed=42, n_reads=4000, rng=1)
+        model, _ = tdlib.build_model(segs, hc, ho, 0.05, float(g["d"]))
+        c.upload_model(model)
+        c.set_params(thr, int(g["minlen"]), int(g["dust"]))
+        st = tdlib.stream_run(c, sam, segs, str(tmp_path / "gpu"), batch_reads=1000, n_threads=2, block_bytes=30000)
+    finally:
+        c.close()
+    assert st["n_reads"] == len(names)
+    a, b = _files(str(tmp_path), "cpu"), _files(str(tmp_path), "gpu")
+    assert a and set(a) == set(b)
+    for k in a:
+        assert a[k] == b[k], "output file *%s differs" % k
