@@ -161,7 +161,7 @@ extern "C" int td_reads_parse(const char* text, int64_t len, int32_t n_threads, 
 			const int64_t so = seq_off[(size_t)k];
 			uint8_t* dst = r->codes + r->offs[k];
 			const int64_t l = r->offs[k + 1] - r->offs[k];
-			for (int64_t j = 0; j < l; j++) dst[j] = kCode.t[(unsigned char)text[so + j]];
+			td_encode_bases((const unsigned char*)text + so, dst, l);
 		}
 	};
 	if (n_threads == 1 || n < 65536) encode(0, n);

@@ -679,7 +679,6 @@ struct Pipeline {
 			struct Job { Batch* b; size_t piece; };
 			std::vector<Job> jobs;
 			std::vector<Batch*> full;
-			const uint8_t* code = td_nuc_code_ptr;
 			double t_seg = t0;
 			auto flush = [&]() -> bool {
 				const double tf0 = now_s();
@@ -712,7 +711,7 @@ struct Pipeline {
 						if (q.seq_off < 0) continue;
 						uint8_t* dst = sb.b->codes + sb.b->offs[pc.first + (r - pc.lo)];
 						const unsigned char* sq = (const unsigned char*)pc.blk->data + q.seq_off;
-						for (int32_t j = 0; j < q.seq_len; j++) dst[j] = code[sq[j]];
+						td_encode_bases(sq, dst, q.seq_len);
 					}
 				});
 				jobs.clear();
