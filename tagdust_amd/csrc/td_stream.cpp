@@ -557,6 +557,19 @@ struct Pipeline {
 	std::string err;
 	std::mutex err_mu;
 	std::unique_ptr<Pool> parse_pool, write_pool;
+	// Appends run beside the formatting of the next batch: every append is a pwrite at an offset fixed when the batch was
+	// formatted, so the order in which they reach the files is free.  Two sets of formatted text; a set is reused once its
+	// appends have been written (append_wait).
+	struct Wr { size_t file, k0, k1; int64_t at; };
+	struct AppendJob { int set; std::vector<Wr> wr; };
+	std::unique_ptr<Pool> append_pool;
+	std::thread appender;
+	std::mutex ap_mu;
+	std::condition_variable ap_cv;
+	std::deque<AppendJob> ap_jobs;
+	bool ap_busy[2] = { false, false }, ap_stop = false, ap_started = false;
+	int ap_errno = 0, ap_set = 0;
+	std::vector<OutBufs> ap_bufs[2];
 	std::unique_ptr<Queue<Batch*>> ready, done, free_list;
 	std::vector<Batch*> all;
 	std::vector<int> fds;
@@ -755,9 +768,70 @@ struct Pipeline {
 		ready->close();
 	}
 
-	// format the records of one batch per output file (on the write pool) and append them in input order
-	bool write_batch(Batch* b, std::vector<OutBufs>& bufs, const int32_t* ctype, const int32_t* cbar, size_t file_base)
+	void append_loop()
 	{
+		for (;;) {
+			AppendJob job;
+			{
+				std::unique_lock<std::mutex> lk(ap_mu);
+				ap_cv.wait(lk, [&] { return ap_stop || !ap_jobs.empty(); });
+				if (ap_jobs.empty()) return;
+				job = std::move(ap_jobs.front());
+				ap_jobs.pop_front();
+			}
+			const double t0 = now_s();
+			const std::vector<OutBufs>& bufs = ap_bufs[job.set];
+			std::vector<int> wrc(job.wr.size(), 0);
+			append_pool->run((int64_t)job.wr.size(), [&](int64_t t) {
+				const Wr& w = job.wr[(size_t)t];
+				int64_t at = w.at;
+				for (size_t k = w.k0; k < w.k1; k++) {
+					const Bytes& sb = bufs[k].file[w.file];
+					size_t off = 0;
+					while (off < sb.n) {
+						const ssize_t r = pwrite(fds[w.file], sb.p + off, sb.n - off, (off_t)(at + (int64_t)off));
+						if (r < 0) { if (errno == EINTR) continue; wrc[(size_t)t] = errno ? errno : EIO; return; }
+						off += (size_t)r;
+					}
+					at += (int64_t)sb.n;
+				}
+			});
+			std::lock_guard<std::mutex> lk(ap_mu);
+			dbg_pwrite += now_s() - t0;
+			for (int e : wrc) if (e && !ap_errno) ap_errno = e;
+			ap_busy[job.set] = false;
+			ap_cv.notify_all();
+		}
+	}
+	// waits until the appends of `set` (-1: of every set) are in the files; false if one of them failed
+	bool append_wait(int set)
+	{
+		std::unique_lock<std::mutex> lk(ap_mu);
+		ap_cv.wait(lk, [&] { return set < 0 ? (!ap_busy[0] && !ap_busy[1]) : !ap_busy[set]; });
+		if (ap_errno) { const int e = ap_errno; lk.unlock(); fail(std::string("td_stream_run: write failed: ") + strerror(e)); return false; }
+		return true;
+	}
+	void append_stop()
+	{
+		{ std::lock_guard<std::mutex> lk(ap_mu); ap_stop = true; }
+		ap_cv.notify_all();
+		if (appender.joinable()) appender.join();
+	}
+	~Pipeline() { append_stop(); }
+
+	// format the records of one batch per output file (on the write pool) and hand the appends (in input order per file) to the
+	// appender thread; append_wait(-1) before the files are closed
+	bool write_batch(Batch* b, const int32_t* ctype, const int32_t* cbar, size_t file_base)
+	{
+		if (!ap_started) {
+			ap_started = true;
+			append_pool.reset(new Pool(write_pool->size()));
+			appender = std::thread([this] { append_loop(); });
+		}
+		const int set = ap_set;
+		ap_set ^= 1;
+		if (!append_wait(set)) return false;
+		std::vector<OutBufs>& bufs = ap_bufs[set];
 		const double t0 = now_s();
 		const int W = write_pool->size();
 		struct Sub { size_t piece; int64_t lo, hi; };
@@ -779,7 +853,6 @@ struct Pipeline {
 		// Appends.  Buffered writes to one file serialise on its inode lock (8 threads on one file: 8 GB/s; one thread on each of
 		// nine files: 56 GB/s, tools/ubench/file_write.cpp), so a file gets one task that appends its share of every sub-range
 		// in order -- or a few tasks over runs of sub-ranges when it takes most of the bytes (no barcode segment: two files)
-		struct Wr { size_t file, k0, k1; int64_t at; };
 		std::vector<Wr> wr;
 		int64_t total_bytes = 0;
 		std::vector<int64_t> per_file(fds.size(), 0);
@@ -805,23 +878,14 @@ struct Pipeline {
 			file_off[f] += per_file[f];
 			st.bytes_out += per_file[f];
 		}
-		std::vector<int> wrc(wr.size(), 0);
-		write_pool->run((int64_t)wr.size(), [&](int64_t t) {
-			const Wr& w = wr[(size_t)t];
-			int64_t at = w.at;
-			for (size_t k = w.k0; k < w.k1; k++) {
-				const Bytes& s = bufs[k].file[w.file];
-				size_t off = 0;
-				while (off < s.n) {
-					const ssize_t r = pwrite(fds[w.file], s.p + off, s.n - off, (off_t)(at + (int64_t)off));
-					if (r < 0) { if (errno == EINTR) continue; wrc[(size_t)t] = errno ? errno : EIO; return; }
-					off += (size_t)r;
-				}
-				at += (int64_t)s.n;
-			}
-		});
-		dbg_pwrite = dbg_pwrite + (now_s() - t0);
-		for (int e : wrc) if (e) { fail(std::string("td_stream_run: write failed: ") + strerror(e)); return false; }
+		{
+			std::lock_guard<std::mutex> lk(ap_mu);
+			ap_busy[set] = true;
+			ap_jobs.push_back(AppendJob{ set, std::move(wr) });
+		}
+		ap_cv.notify_all();
+		static const bool sync_appends = getenv("TD_STREAM_SYNC_APPENDS") && atoi(getenv("TD_STREAM_SYNC_APPENDS")) != 0;   // A/B: round 3's order
+		if (sync_appends && !append_wait(set)) return false;
 		return true;
 	}
 
@@ -829,11 +893,10 @@ struct Pipeline {
 	void consumer()
 	{
 		Batch* b = nullptr;
-		std::vector<OutBufs> bufs;
 		while (done->pop(b)) {
 			const double t0 = now_s();
 			if (!dry) {
-				if (!write_batch(b, bufs, nullptr, nullptr, 0)) return;
+				if (!write_batch(b, nullptr, nullptr, 0)) return;
 			} else {
 				// parse-only run: a checksum over what would have gone to the device (lengths and codes, in order)
 				for (int64_t i = 0; i < b->n; i++) {
@@ -848,7 +911,13 @@ struct Pipeline {
 			st.write_s += now_s() - t0;
 			if (!free_list->push(b)) return;
 		}
-		if (getenv("TD_STREAM_DEBUG")) fprintf(stderr, "td_stream: formatting %.3f s, appends %.3f s (write stage %.3f s)\n", dbg_format, dbg_pwrite - dbg_format, st.write_s);
+		{
+			const double t0 = now_s();
+			const bool ok = append_wait(-1);
+			st.write_s += now_s() - t0;
+			if (!ok) return;
+		}
+		if (getenv("TD_STREAM_DEBUG")) fprintf(stderr, "td_stream: formatting %.3f s, appends %.3f s beside it (write stage %.3f s)\n", dbg_format, dbg_pwrite, st.write_s);
 	}
 };
 
@@ -972,6 +1041,7 @@ extern "C" int td_stream_run(td_ctx* ctx, const char* in_path, const td_arch* ar
 	p.done->close();
 	t_prod.join();
 	t_cons.join();
+	p.append_stop();                       // (after a failure appends may still be queued: none may outlive the descriptors)
 	{ std::lock_guard<std::mutex> lk(p.all_mu); p.stop_alloc = true; }
 	p.hint_cv.notify_all();
 	p.free_list->abort();          // (an allocator waiting to hand over a batch)
@@ -1159,7 +1229,6 @@ extern "C" int td_stream_run_multi(const td_stream_file* files, int32_t n_files,
 	// ---- writer: run_rna_dust for the files that are not decoded, the per-record combination, print_all ----
 	std::thread t_write([&] {
 		Tuple* t = nullptr;
-		std::vector<OutBufs> bufs;
 		std::vector<int32_t> ctype, cbar;
 		while (done_t.pop(t)) {
 			const double t0 = now_s();
@@ -1190,13 +1259,16 @@ extern "C" int td_stream_run_multi(const td_stream_file* files, int32_t n_files,
 			}
 			bool ok = true;
 			for (int k = 0; k < K && ok; k++)
-				if (read_present[(size_t)k] > 0) ok = pw.write_batch(t->b[(size_t)k], bufs, ctype.data(), cbar.data(), file_base[(size_t)k]);
+				if (read_present[(size_t)k] > 0) ok = pw.write_batch(t->b[(size_t)k], ctype.data(), cbar.data(), file_base[(size_t)k]);
 			pw.st.n_reads += n; pw.st.n_batches++;
 			pw.st.write_s += now_s() - t0;
 			for (int k = 0; k < K; k++) { t->b[(size_t)k]->pieces.clear(); t->b[(size_t)k]->seq_src = nullptr; (void)pf[(size_t)k]->free_list->push(t->b[(size_t)k]); }
 			delete t;
 			if (!ok) return;
 		}
+		const double t0 = now_s();
+		(void)pw.append_wait(-1);
+		pw.st.write_s += now_s() - t0;
 	});
 	// ---- the calling thread: one record range of every file at a time, `depth` of them on the devices ----
 	std::deque<Tuple*> flying;
@@ -1282,6 +1354,7 @@ extern "C" int td_stream_run_multi(const td_stream_file* files, int32_t n_files,
 	}
 	done_t.close();
 	t_write.join();
+	pw.append_stop();
 	for (int k = 0; k < K; k++) {
 		Pipeline& p = *pf[(size_t)k];
 		if (pw.failed()) p.fail(pw.err);
