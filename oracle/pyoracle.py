@@ -92,6 +92,40 @@ def bound_margins(model, seqs, offs, info):
     return out
 
 
+def lead_profile(model, seqs, offs, n_seg, floor=-103.98):
+    """(last position with a posterior term of the first n_seg segments above `floor`, per read; per position: the largest such
+    term, the largest forward value, the largest backward value - b_score -- rows of the second result)"""
+    L = lib()
+    L.tdo_lead_profile.restype = C.c_int
+    L.tdo_lead_profile.argtypes = [C.POINTER(_Model), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int]
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.int64)
+    n = len(offs) - 1
+    last = np.zeros(n, np.int32)
+    plen = int(np.diff(offs).max()) + 2
+    prof = np.zeros(3 * plen, np.float32)
+    rc = L.tdo_lead_profile(C.byref(model.c), seqs.ctypes.data, offs.ctypes.data, n, int(n_seg), float(floor), last.ctypes.data, prof.ctypes.data, plen)
+    if rc != 0:
+        raise RuntimeError("tdo_lead_profile failed (%d)" % rc)
+    return last, prof.reshape(3, plen)
+
+
+def lead_class_profile(model, seqs, offs, n_seg):
+    """Per state class of the first n_seg segments (column, M / I; HMMs of a segment together) and position: the largest forward
+    value and the largest backward value - b_score over the reads -- array [classes][2][max_len + 2]."""
+    L = lib()
+    L.tdo_lead_class_profile.restype = C.c_int
+    L.tdo_lead_class_profile.argtypes = [C.POINTER(_Model), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.int64)
+    plen = int(np.diff(offs).max()) + 2
+    out = np.zeros(256 * 2 * plen, np.float32)
+    nc = L.tdo_lead_class_profile(C.byref(model.c), seqs.ctypes.data, offs.ctypes.data, len(offs) - 1, int(n_seg), out.ctypes.data, plen, 256)
+    if nc < 0:
+        raise RuntimeError("tdo_lead_class_profile failed")
+    return out[:nc * 2 * plen].reshape(nc, 2, plen).copy()
+
+
 def restart_margins(model, seqs, offs, n_seg, sfx_first, gq, gf):
     """Smallest margins by which the start of the device kernel's restarted sweeps (tagdust_amd.lib.spec_restart_info()) dominates
     the backward values of the leading / the forward values of the trailing segments the oracle computes: [backward, forward]."""

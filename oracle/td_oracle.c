@@ -731,6 +731,97 @@ int tdo_bound_margins(const tdo_model* m, const uint8_t* seqs, const int64_t* of
 	return 0;
 }
 
+/* How far into a read the leading segments' posteriors really reach (tools/cut_slack.py: the slack of the device kernel's
+ * bound-based pruning cut): for every read the last position at which some M / I state of the first n_seg segments has
+ * forward + backward - b_score above `floor_` (the reference's posterior is exactly 0.0f below -103.98), into last_pos[r]
+ * (0: none); prof[i] = the largest such term at position i over all reads; prof has 3 x prof_len entries (prof_len >= max_len + 1):
+ * the terms, then the largest forward value and the largest (backward - b_score) per position. */
+int tdo_lead_profile(const tdo_model* m, const uint8_t* seqs, const int64_t* offs, int64_t n_reads, int n_seg, float floor_,
+                     int32_t* last_pos, float* prof, int prof_len)
+{
+	float* const pf = prof + prof_len;          /* [prof_len .. 2 prof_len): largest forward value, then largest backward - b_score */
+	float* const pb = prof + 2 * prof_len;
+	for (int i = 0; i < 2 * prof_len; i++) pf[i] = NEG_INF;
+	int max_len = 1;
+	for (int64_t r = 0; r < n_reads; r++) if (offs[r + 1] - offs[r] > max_len) max_len = (int)(offs[r + 1] - offs[r]);
+	if (n_seg < 1 || n_seg >= m->S || prof_len < max_len + 1) return -1;
+	tdo_workspace* ws = tdo_workspace_new(m, max_len);
+	if (!ws) return -1;
+	int8_t* labels = (int8_t*)malloc((size_t)max_len + 2);
+	for (int i = 0; i < prof_len; i++) prof[i] = NEG_INF;
+	const int st = ws->stride;
+	const int c_end = m->col_off[n_seg];
+	for (int64_t r = 0; r < n_reads; r++) {
+		const uint8_t* seq = seqs + offs[r];
+		const int len = (int)(offs[r + 1] - offs[r]);
+		last_pos[r] = 0;
+		if (len < 1) continue;
+		float f, rs, bp;
+		const float b = tdo_backward(m, ws, seq, len);
+		if (!(b > NEG_INF)) continue;
+		tdo_forward_decode(m, ws, seq, len, b, &f, &rs, &bp, labels);
+		for (int c = 0; c < c_end; c++)
+			for (int i = 1; i <= len; i++) {
+				const float tm = ws->MF[c * st + i] + ws->MB[c * st + i] - b, ti = ws->IF[c * st + i] + ws->IB[c * st + i] - b;
+				const float t = tm > ti ? tm : ti;
+				const float vf = ws->MF[c * st + i] > ws->IF[c * st + i] ? ws->MF[c * st + i] : ws->IF[c * st + i];
+				const float vb = (ws->MB[c * st + i] > ws->IB[c * st + i] ? ws->MB[c * st + i] : ws->IB[c * st + i]) - b;
+				if (vf > pf[i]) pf[i] = vf;
+				if (vb > pb[i]) pb[i] = vb;
+				if (t > prof[i]) prof[i] = t;
+				if (t > floor_ && i > last_pos[r]) last_pos[r] = i;
+			}
+	}
+	free(labels);
+	tdo_workspace_free(ws);
+	return 0;
+}
+
+/* Per state class (column g of leading segment j, M or I; the HMMs of a segment taken together): the largest forward value and the
+ * largest (backward - b_score) per position over all reads -- out[((cls * 2 + which) * prof_len) + i], cls = 2 * (column index
+ * within the leading segments, HMMs folded) + (0 M, 1 I), which = 0 forward, 1 backward.  Returns the number of classes, -1 on error. */
+int tdo_lead_class_profile(const tdo_model* m, const uint8_t* seqs, const int64_t* offs, int64_t n_reads, int n_seg, float* out, int prof_len, int max_cls)
+{
+	int max_len = 1;
+	for (int64_t r = 0; r < n_reads; r++) if (offs[r + 1] - offs[r] > max_len) max_len = (int)(offs[r + 1] - offs[r]);
+	int ncls = 0;
+	for (int j = 0; j < n_seg; j++) ncls += 2 * m->n_col[j];
+	if (n_seg < 1 || n_seg >= m->S || prof_len < max_len + 1 || ncls > max_cls) return -1;
+	tdo_workspace* ws = tdo_workspace_new(m, max_len);
+	if (!ws) return -1;
+	int8_t* labels = (int8_t*)malloc((size_t)max_len + 2);
+	for (int64_t i = 0; i < (int64_t)ncls * 2 * prof_len; i++) out[i] = NEG_INF;
+	const int st = ws->stride;
+	for (int64_t r = 0; r < n_reads; r++) {
+		const uint8_t* seq = seqs + offs[r];
+		const int len = (int)(offs[r + 1] - offs[r]);
+		if (len < 1) continue;
+		float f, rs, bp;
+		const float b = tdo_backward(m, ws, seq, len);
+		if (!(b > NEG_INF)) continue;
+		tdo_forward_decode(m, ws, seq, len, b, &f, &rs, &bp, labels);
+		int cbase = 0;
+		for (int j = 0; j < n_seg; j++) {
+			for (int h = 0; h < m->n_hmm[j]; h++)
+				for (int g = 0; g < m->n_col[j]; g++) {
+					const int c = m->col_off[j] + h * m->n_col[j] + g;
+					for (int i = 1; i <= len; i++) {
+						float* o = out + (int64_t)(2 * (cbase + g)) * 2 * prof_len;
+						if (ws->MF[c * st + i] > o[i]) o[i] = ws->MF[c * st + i];
+						if (ws->MB[c * st + i] - b > o[prof_len + i]) o[prof_len + i] = ws->MB[c * st + i] - b;
+						o += 2 * prof_len;
+						if (ws->IF[c * st + i] > o[i]) o[i] = ws->IF[c * st + i];
+						if (ws->IB[c * st + i] - b > o[prof_len + i]) o[prof_len + i] = ws->IB[c * st + i] - b;
+					}
+				}
+			cbase += m->n_col[j];
+		}
+	}
+	free(labels);
+	tdo_workspace_free(ws);
+	return ncls;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * The same for the start of the device kernel's restarted sweeps (td_spec_kernel.inc "Restarted sweeps"): gq[j] / gf[t] are the
  * host's impulse-response tables (tagdust_amd.lib.spec_restart_info: leading segments 0..3, then the first four trailing

@@ -144,4 +144,8 @@ int   tdo_bound_margins(const tdo_model* m, const uint8_t* seqs, const int64_t* 
 #ifdef __cplusplus
 }
 #endif
+/* tools/cut_slack.py: last position with a leading-segment posterior term above floor_ per read, and the largest term per position */
+int   tdo_lead_class_profile(const tdo_model* m, const uint8_t* seqs, const int64_t* offs, int64_t n_reads, int n_seg, float* out, int prof_len, int max_cls);
+int   tdo_lead_profile(const tdo_model* m, const uint8_t* seqs, const int64_t* offs, int64_t n_reads, int n_seg, float floor_,
+                       int32_t* last_pos, float* prof, int prof_len);
 #endif
