@@ -4,7 +4,7 @@
 # (tools/tsan_stream/stub.cpp), a 60 000-read ragged FASTQ file in batches of 777 reads and blocks of 20 KB -- parse-only and
 # with the stubbed decode + real formatting / appends, each twice (the second run reuses the cached batch buffers), and the
 # multi-file pipeline (td_stream_run_multi: two input files in lock-step, two "devices", one file not decoded).
-# usage: tools/tsan_stream.sh      (prints the four result lines; any ThreadSanitizer report goes to stderr)
+# usage: tools/tsan_stream.sh      (prints the result lines, the last one of a run into a full disk; any ThreadSanitizer report goes to stderr)
 set -e
 cd "$(dirname "$0")/.."
 OUT=/tmp/td_tsan
@@ -19,3 +19,8 @@ with open('/tmp/td_tsan/in.fq', 'wb') as f:
 PY
 cd $OUT
 for mode in "" decode multi; do ./tsan_stream in.fq 777 4 20000 $mode; done
+# a full disk: every output file a link to /dev/full -- the appender thread's pwrite fails, the run must end with TD_FAIL and
+# "write failed" (not hang, not report success)
+for f in out_*.fq; do rm -f $f; ln -s /dev/full $f; done
+timeout 120 ./tsan_stream in.fq 777 4 20000 decode | head -1
+rm -f out_*.fq

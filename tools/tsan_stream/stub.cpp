@@ -51,7 +51,8 @@ int main(int argc, char** argv)
 	}
 	for (int rep = 0; rep < 2; rep++) {
 		int rc = td_stream_run(argc > 5 ? (td_ctx*)0x1 : nullptr, argv[1], a, "/tmp/td_tsan/out", &o, &st);
-		printf("rc %d reads %lld batches %lld bytes_out %lld fnv %llx\n", rc, (long long)st.n_reads, (long long)st.n_batches, (long long)st.bytes_out, (unsigned long long)st.codes_fnv);
+		printf("rc %d reads %lld batches %lld bytes_out %lld fnv %llx%s%s\n", rc, (long long)st.n_reads, (long long)st.n_batches, (long long)st.bytes_out, (unsigned long long)st.codes_fnv,
+		       rc ? "  error: " : "", rc ? td_io_last_error() : "");
 	}
 	td_stream_release();
 	return 0;
