@@ -536,3 +536,31 @@ def test_sam_stream_equals_the_reference_binary(tmp_path, monkeypatch, name):
     assert a and set(a) == set(b)
     for k in a:
         assert a[k] == b[k], "output file *%s differs" % k
+
+
+@pytest.mark.gpu
+def test_a_full_disk_fails_the_run(tmp_path):
+    """Every output file a link to /dev/full: the appender thread's pwrite comes back with ENOSPC while the next batch is being
+    formatted; the run must end with an error that says so (not hang, not report success)."""
+    from test_dropin_gpu import _write_fastq
+    from tagdust_amd import TagdustHip, TdError
+    from tagdust_amd import lib as tdlib
+    g = load_golden("c2_b4_r")
+    fq = str(tmp_path / "in.fq")
+    _write_fastq(g, fq)
+    segs = _segments(g)
+    c = TagdustHip(0)
+    try:
+        c.upload_model(g)
+        c.set_params(float(g["threshold"]), int(g["minlen"]), int(g["dust"]))
+        st = tdlib.stream_run(c, fq, segs, str(tmp_path / "out"), batch_reads=50, n_threads=2, block_bytes=4096)
+        assert st["n_reads"] == int(g["n_reads"])
+        made = sorted(glob.glob(str(tmp_path / "out*.fq")))
+        assert made
+        for p in made:
+            os.remove(p)
+            os.symlink("/dev/full", p)
+        with pytest.raises(TdError, match="write failed"):
+            tdlib.stream_run(c, fq, segs, str(tmp_path / "out"), batch_reads=50, n_threads=2, block_bytes=4096)
+    finally:
+        c.close()
