@@ -185,3 +185,30 @@ def test_fasta_parse_matches_reference_read_fasta():
     assert len(ix2) == 1 and ix2[0] == 0 and names2 == []
     st3, ix3, _ = tdlib.parse_fasta(b">only_a_header\n")
     assert ix3.tolist() == [0, 1] and st3.tolist() == [ord("X")]
+
+
+def test_base_coding_of_every_byte_value_and_length():
+    """td_encode_bases (sixteen letters at a time, an overlapping last block) against init_nuc_code's table (nuc_code.c:46-74) spelled
+    out here: every byte value a sequence line can hold (32..255 without 127), at every length 1..70 and every phase within a block."""
+    from tagdust_amd import lib as tdlib
+    table = np.full(256, 4, np.uint8)
+    for ch, v in (("A", 0), ("a", 0), ("C", 1), ("c", 1), ("G", 2), ("g", 2), ("T", 3), ("t", 3), ("U", 3), ("u", 3), (".", 5)):
+        table[ord(ch)] = v
+    allowed = np.array([b for b in range(32, 256) if b != 127], np.uint8)
+    rng = np.random.RandomState(4)
+    recs, want = [], []
+    for L in range(1, 71):
+        for rep in range(6):
+            s = allowed[(np.arange(L) * (rep + 1) + rng.randint(0, len(allowed))) % len(allowed)] if rep < 3 else rng.choice(allowed, L)
+            if s[0] in (ord("@"), ord("+"), ord(">")):
+                s[0] = ord("A")                     # (a sequence line does not start a record or a separator)
+            recs.append(b"@r%d_%d\n" % (L, rep) + s.tobytes() + b"\n+\n" + b"I" * L + b"\n")
+            want.append(table[s])
+    text = b"".join(recs)
+    for threads in (1, 3):
+        pr = tdlib.ParsedReads(text, threads)
+        assert pr.n == len(want)
+        for i, w in enumerate(want):
+            got = pr.codes[pr.offs[i]:pr.offs[i + 1]]
+            assert np.array_equal(got, w), (i, got[:20], w[:20])
+        pr.close()
