@@ -628,7 +628,18 @@ def main():
     # host threads of the library's copy pool (pageable caller memory <-> pinned staging, rebuilding sequences and labels from the
     # compact egress): the rank's share of the CPUs, at most 16 (the decode launch takes 15 ms per 2^20 reads now: the host's
     # 12 ms per step on 8 threads no longer hide behind it with room to spare)
-    os.environ.setdefault("TD_HOST_THREADS", str(max(2, min(16, host["cpus"] // 2))))
+    nthr = max(2, min(16, host["cpus"] // 2))
+    if local_world > 1:
+        # several ranks on one host share what the job may really use: a cgroup CPU quota below the affinity mask's width (the
+        # pool's boxes: 16 of 256) must not be oversubscribed N times over -- every rank takes its share of it
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                nthr = max(2, min(nthr, int(float(q) / float(per)) // local_world))
+        except Exception:
+            pass
+    host["copy_threads"] = nthr
+    os.environ.setdefault("TD_HOST_THREADS", str(nthr))
     dist = None
     use_dist = world > 1 or os.environ.get("TD_BENCH_FORCE_DIST") == "1"   # the latter: a 1-rank RCCL group on a one-GPU box
     if use_dist:
