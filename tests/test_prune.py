@@ -272,7 +272,7 @@ def test_pruning_on_ragged_short_and_dead_reads():
         assert np.array_equal(res[k], ores[k]), k
 
 
-_LONG_SEEDS = list(range(10))
+_LONG_SEEDS = list(range(10)) + [455]     # 455: the architecture an alternative machine scheduler miscompiled (td_jit.hip, TD_SPEC_SCHED)
 if os.environ.get("TD_FUZZ_SEEDS"):      # e.g. TD_FUZZ_SEEDS=100:400 for a longer one-off run
     _a, _b = os.environ["TD_FUZZ_SEEDS"].split(":")
     _LONG_SEEDS = list(range(int(_a), int(_b)))

@@ -27,8 +27,8 @@ def check(name="c3_b6_s_r_p", keep=False, outdir="/tmp/td_spec"):
         cmd += ["-fno-slp-vectorize"]      # as td_jit.hip compiles it
     if os.environ.get("TD_SPEC_MLICM", "0") == "0":
         cmd += ["-mllvm", "-disable-machine-licm"]
-    if os.environ.get("TD_SPEC_SCHED", "iterative-ilp") not in ("", "default"):
-        cmd += ["-mllvm", "-amdgpu-sched-strategy=" + os.environ.get("TD_SPEC_SCHED", "iterative-ilp")]
+    if os.environ.get("TD_SPEC_SCHED", "default") not in ("", "default"):
+        cmd += ["-mllvm", "-amdgpu-sched-strategy=" + os.environ["TD_SPEC_SCHED"]]
     cmd += os.environ.get("TD_SPEC_EXTRA_OPTS", "").split()
     if keep:
         cmd += ["-save-temps=obj"]
