@@ -583,7 +583,9 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS), help="development only; the bench line is c3")
     ap.add_argument("--specialize", type=int, default=1, help="0 = generic ahead-of-time kernel")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight (td_submit pipeline depth)")
-    ap.add_argument("--pinned", type=int, default=0, help="1 = the caller's buffers are page-locked (td_host_alloc): no host copies at all")
+    ap.add_argument("--pinned", type=int, default=1, help="1 = the caller's buffers are page-locked (td_host_alloc, under stable_input): no staging copies on the host -- the headline "
+                    "since the end of round 4 (a rank's host work and DRAM traffic are what eight ranks share on one node; at one GPU the two modes are equal within "
+                    "the box-to-box spread); 0 = pageable numpy arrays, staged through the library's pinned memory (the headline of rounds 3-4, reported beside it)")
     ap.add_argument("--labels", type=int, default=1, help="0 = the timed region does not download the per-base labels (rounds 1-2)")
     ap.add_argument("--sustained", type=int, default=200, help="steps of the extra sustained run (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="0 = skip the extra measurements (kernel only, pinned I/O, configs 2 and 5)")
@@ -793,11 +795,13 @@ def main():
         }
         extra["kernel_only"] = iso
     close()
+    other_key = "pageable_io" if args.pinned else "pinned_io"
+    other_buffers = "pageable numpy arrays (library stages through pinned memory)" if args.pinned else "page-locked (td_host_alloc)"
     if args.extras and world > 1:
-        # every rank again with page-locked caller buffers (td_host_alloc): no staging copies on the host at all -- beside the
-        # headline's pageable buffers, so that a host-side limit of the N-GPU run shows up as the difference between the two
+        # every rank again with the other kind of caller buffers (pageable: staged through the library's pinned memory; page-locked:
+        # no staging copies at all), so that a host-side limit of the N-GPU run shows up as the difference between the two
         try:
-            c2, m2, go2, st2, ko2, close2, _ = measure_workload(args.workload, n, 12, 3, dev_index, args.specialize, args.depth, True,
+            c2, m2, go2, st2, ko2, close2, _ = measure_workload(args.workload, n, 12, 3, dev_index, args.specialize, args.depth, not args.pinned,
                                                                  check=0, kernel_only_steps=0, labels=bool(args.labels))
             c2.sync(); dist.barrier()
             t1 = time.perf_counter()
@@ -807,15 +811,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             close2()
             if rank == 0:
-                extra["pinned_io"] = {"value": n * 12 * world / float(t.item()), "unit": "reads/s", "steps": 12, "host_buffers": "page-locked (td_host_alloc)",
-                                      "note": "all ranks, max over ranks; the headline uses pageable buffers"}
+                extra[other_key] = {"value": n * 12 * world / float(t.item()), "unit": "reads/s", "steps": 12, "host_buffers": other_buffers,
+                                    "note": "all ranks, max over ranks; the headline uses the other kind of caller buffers (config.host_buffers)"}
         except Exception as e:
             if rank == 0:
-                extra["pinned_io"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                extra[other_key] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and args.extras and world == 1:
         # beside the headline: the same pipeline with page-locked caller buffers, and BASELINE configs[1] / configs[4]
         # (parity-test cases per the contract, timed here so that their rates are on the driver's record)
-        for key, wl, nn, st, pin in (("c3_pinned_io", args.workload, n, args.steps, True), ("config2", "c2", n, 16, False),
+        for key, wl, nn, st, pin in (("c3_" + other_key, args.workload, n, args.steps, not args.pinned), ("config2", "c2", n, 16, False),
                                      ("config5", "c5", n // 4, 8, False)):
             try:
                 c2, m2, go2, st2, ko2, close2, _ = measure_workload(wl, nn, st, 3, dev_index, args.specialize, args.depth, pin,
